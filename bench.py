@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Benchmark of the LMIP sub-volume march on MI355X (BASELINE.json metric).
+
+A *step* of this bench is one frame: one pass of the hot path (``svr_render``:
+vs_main + fs_main + raycast of the reference's WGSL as one HIP kernel) over all
+rays of a 1920x1080 frame of BASELINE config 2 — 1024^3 uint8 density + uint32
+labels, 3 LODs, chunk shapes (16,16,48)/(8,8,48)/(4,4,48), ring shapes
+(32,32,11)/(64,64,11)/(64,64,6) chunks (2.36 GB of ring textures), camera K1
+(SURVEY.md §8d).  Ring buffers are resident in HBM before the timed region.
+
+``value`` = ray-steps of the frame / frame time in *full* march mode (threshold =
++inf: every ray runs all its nsteps; the deterministic roofline number).  The
+realistic early-out LMIP mode (threshold 0.5) is reported in the ``lmip`` block.
+
+N > 1 (launched by torch.distributed.run): ring buffers replicated per GPU, the
+frame dealt to ranks in interleaved row bands, one RCCL gather of the RGBA bands
+to rank 0 + an un-tile kernel per frame; strong scaling (one frame, N GPUs).
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1024, help="volume edge (config 2: 1024)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--camera", choices=["K1", "K2"], default="K1")
+    ap.add_argument("--band-h", type=int, default=16)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=0, help="oracle sample: every k-th row (0 = auto)")
+    ap.add_argument("--check", action="store_true", help="also compare the sampled rows with the oracle")
+    return ap.parse_args()
+
+
+def config2_spec(n, width, height, camera, pairs):
+    from sub_volume_renderer_amd import testing
+
+    s = n / 1024.0
+    ring_shapes = [(max(2, round(32 * s)), max(2, round(32 * s)), max(2, round(11 * s))),
+                   (max(2, round(64 * s)), max(2, round(64 * s)), max(2, round(11 * s))),
+                   (max(2, round(64 * s)), max(2, round(64 * s)), max(2, round(6 * s)))]
+    spec = testing.synthetic_spec(
+        n, width, height, inside=(camera == "K2"), threshold=0.5, fog_density=0.01, ncolors=4,
+        chunk_shapes=[(16, 16, 48), (8, 8, 48), (4, 4, 48)], ring_shapes=ring_shapes,
+        sizes=[None, (n // 2,) * 3, (n // 4,) * 3], pairs=pairs)
+    # LOD0: default window (N-1)*C around the centre; LOD1/2: their whole level
+    r0 = ring_shapes[0]
+    c0 = spec.chunk_shapes[0]
+    size0 = tuple((a - 1) * b for a, b in zip(r0, c0))
+    spec.centers = [(spec.centers[0][0], [size0, (n // 2,) * 3, (n // 4,) * 3])]
+    return spec
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if rank == 0:
+        g.build_hip()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    from sub_volume_renderer_amd import FrameRegion, Roi, _native as N, synth, testing
+
+    dev = torch.device("cuda", local_rank)
+    n, W, H = args.n, args.width, args.height
+    t0 = time.time()
+    pairs = [synth.volume(n, k, 4096, xp=torch, device=dev, slab=16 if n >= 512 else 64) for k in range(3)]
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    spec = config2_spec(n, W, H, args.camera, pairs)
+    t0 = time.time()
+    scene = testing.build(spec, device=local_rank)
+    scene.volume.synchronize()
+    t_load = time.time() - t0
+    vol, cam = scene.volume, scene.camera
+    N.check(N.lib().svr_set_variant(vol._rings.handle, args.variant), "svr_set_variant")
+
+    region = FrameRegion.full(W, H) if world == 1 else FrameRegion.stripes(W, H, rank, world, args.band_h)
+    full_frame = FrameRegion.full(W, H)
+
+    def set_mode(full):
+        vol.material.lmip_threshold = float("inf") if full else 0.5 * 255.0
+
+    # ---- exact step / hit / pixel counts of the whole frame (instrumented kernel, untimed)
+    counts = {}
+    for mode in ("full", "lmip"):
+        set_mode(mode == "full")
+        r = vol.render(cam, W, H, region=full_frame, count_steps=True)
+        torch.cuda.synchronize()
+        counts[mode] = dict(steps=int(r.steps.to(torch.int64).sum().item()),
+                            hits=int((r.flags == 2).sum().item()),
+                            frags=int((r.flags != 0).sum().item()))
+    vol._out_cache = {}
+
+    # ---- outputs for the timed loop
+    out = vol._outputs(region.out_h, region.out_w, False)
+    gathered = frame_rgba = None
+    if world > 1 and rank == 0:
+        gathered = torch.empty((world, region.out_h, W, 4), dtype=torch.float32, device=dev)
+        frame_rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def frame():
+        res = vol.render(cam, W, H, region=region, out=out)
+        if world > 1:
+            dist.gather(res.rgba, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                N.check(N.lib().svr_untile_stripes(vol._rings.handle, C.c_void_p(gathered.data_ptr()),
+                                                   C.c_void_p(frame_rgba.data_ptr()), W, H, args.band_h, world,
+                                                   region.out_h, 16, C.c_void_p(stream.cuda_stream)), "untile")
+
+    def timed(mode, steps, warmup):
+        set_mode(mode == "full")
+        for _ in range(warmup):
+            frame()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt_full = timed("full", args.steps, args.warmup)
+    dt_lmip = timed("lmip", args.steps, args.warmup)
+
+    # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
+    def kernel_ms(mode, iters=10):
+        set_mode(mode == "full")
+        vol.prepare()
+        cb, fb = vol.camera_block(cam), vol.frame_block(W, H, region)
+        ob = N.Outputs()
+        ob.rgba, ob.depth, ob.label, ob.flags, ob.steps = (out.rgba.data_ptr(), out.depth.data_ptr(),
+                                                           out.label.data_ptr(), out.flags.data_ptr(), None)
+        ms = C.c_float(0)
+        N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)),
+                "svr_time_render")
+        return float(ms.value)
+
+    torch.cuda.synchronize()
+    k_full = kernel_ms("full")
+    k_lmip = kernel_ms("lmip")
+
+    def algo_bytes(c, npix):
+        # 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
+        # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
+        return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
+
+    result = None
+    if world == 1:
+        npix = W * H
+        a_full = algo_bytes(counts["full"], npix) / (k_full * 1e-3) / 1e9
+        a_lmip = algo_bytes(counts["lmip"], npix) / (k_lmip * 1e-3) / 1e9
+    if rank == 0:
+        ms_full = dt_full / args.steps * 1e3
+        ms_lmip = dt_lmip / args.steps * 1e3
+        result = {
+            "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
+            "value": counts["full"]["steps"] / (dt_full / args.steps) / 1e6,
+            "unit": "Mray-steps/s",
+            "frames_per_s": args.steps / dt_full,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_full,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {n}^3 u8 density + u32 labels, 3 LODs, chunks (16,16,48)/(8,8,48)/(4,4,48), "
+                            f"rings {spec.ring_shapes} chunks, {W}x{H}, camera {args.camera}, march_mode=full",
+                "ray_steps_per_frame": counts["full"]["steps"],
+                "rays_with_fragment": counts["full"]["frags"],
+                "parallelism": "single" if world == 1 else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
+                "kernel_variant": args.variant,
+            },
+            "lmip": {
+                "march_mode": "lmip threshold=0.5*255 fall_off=0.5 max_samples=10",
+                "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
+                "value": counts["lmip"]["steps"] / (dt_lmip / args.steps) / 1e6, "unit": "Mray-steps/s",
+                "frames_per_s": args.steps / dt_lmip, "ms_per_step": ms_lmip,
+            },
+            "setup_s": {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)},
+        }
+        if world == 1:
+            result["roofline"] = {
+                "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": a_full / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "march (full mode)", "kernel_ms": k_full,
+                "algorithmic_bytes": algo_bytes(counts["full"], W * H),
+            }
+            result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": k_lmip}
+
+    # ---- CPU baseline: the oracle (a port: the reference itself cannot run offline) on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import lmip as oracle_lmip
+
+        rings = []
+        for b in vol.wrapping_buffers:
+            d, l = b.read_ring(Roi((0, 0, 0), b.shape_in_pixels))
+            u = b.uniform_buffer.data
+            rings.append(dict(density=d, labels=l,
+                              offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
+                              shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
+                              scale=tuple(float(v) for v in u["scale_factor"])))
+        stride = args.cpu_row_stride or max(1, int(round(16 * (n / 1024.0) ** 1)))
+        nrows = -(-H // stride)
+        sample = FrameRegion(0, 0, W, nrows, 1, stride)
+        mats = spec.matrices()
+        vdim = tuple(float(v) for v in vol._volume_dimensions)
+        base = {}
+        for mode in ("full", "lmip"):
+            m = dict(spec.material)
+            m["lmip_threshold"] = float("inf") if mode == "full" else 0.5 * 255.0
+            t = time.perf_counter()
+            ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=0)
+            dtc = time.perf_counter() - t
+            base[mode] = (int(ref.steps.astype(np.int64).sum()), dtc, ref)
+        cores = oracle_lmip.lib().svr_oracle_max_threads()
+        st, dtc, ref = base["full"]
+        result["cpu_baseline"] = {
+            "value": st / dtc / 1e6, "unit": "Mray-steps/s", "cores": cores, "kind": "port",
+            "sample": f"every {stride}th row of the same frame ({nrows} rows, {st} ray-steps, {dtc:.1f} s), "
+                      "full mode; CPU restatement of the reference shader (reference itself not runnable offline)",
+            "lmip_value": base["lmip"][0] / base["lmip"][1] / 1e6,
+        }
+        if args.check:
+            set_mode(True)
+            res = vol.render(cam, W, H, region=sample, count_steps=True)
+            torch.cuda.synchronize()
+            result["check"] = testing.compare(res, ref)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/*
+ * svr.h — C ABI of the MI355X-native sub-volume LMIP ray-march renderer.
+ *
+ * The reference (gyoge0/sub_volume_renderer) has no FFI boundary of its own:
+ * its hot path sits behind pygfx's plugin hooks — uniform buffers, texture
+ * bindings and a WGSL fragment shader (src/sub_volume/_shader.py:75-127).
+ * This header is the C-ABI replacement of exactly those hooks.  Every entry
+ * point cites the reference interface it replaces.  All vectors at this
+ * boundary are in SHADER ORDER (x, y, z) = reversed numpy order, exactly as
+ * the reference writes them into its uniform buffers
+ * (_wrapping_buffer.py:84-96,113-115; _wobject.py:121-123).  Ring memory is
+ * C-contiguous [z][y][x] (texel (x,y,z) == numpy data[z,y,x], KNOWLEDGE.md:81-133).
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature
+ * (streams travel as void*).  Every function returns 0 on success and a
+ * negative svr_status on failure; svr_last_error() gives the message.
+ */
+#ifndef SVR_H
+#define SVR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVR_MAX_LODS 8
+#define SVR_ABI_VERSION 1
+
+typedef enum svr_status {
+    SVR_OK = 0,
+    SVR_ERR_INVALID = -1,   /* bad argument (maps to ValueError in the Python mirror) */
+    SVR_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SVR_ERR_NOMEM = -3,     /* device or pinned allocation failed */
+    SVR_ERR_RANGE = -4      /* region outside the ring / frame */
+} svr_status;
+
+/* element types accepted for source arrays (np.array(src, dtype=f32/u32) in
+ * _wrapping_buffer.py:325,330 accepts anything numpy can cast) */
+typedef enum svr_dtype {
+    SVR_U8 = 0, SVR_U16 = 1, SVR_U32 = 2, SVR_U64 = 3,
+    SVR_I8 = 4, SVR_I16 = 5, SVR_I32 = 6, SVR_I64 = 7,
+    SVR_F32 = 8, SVR_F64 = 9
+} svr_dtype;
+
+/* One LOD's ring buffer = the two gfx.Texture objects of a WrappingBuffer
+ * (_wrapping_buffer.py:50-59): r32float density + r32uint labels, both of
+ * extent ring_dims (shader order), zero-initialised. */
+typedef struct svr_lod_desc {
+    int32_t ring_dims[3];          /* (x, y, z) voxels = reversed shape_in_pixels */
+} svr_lod_desc;
+
+/* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.
+ * offset == shape == 0 means "ROI is None": nothing is in bounds (:90-96). */
+typedef struct svr_lod_state {
+    int32_t offset[3];             /* current_logical_offset_in_pixels */
+    int32_t shape[3];              /* current_logical_shape_in_pixels  */
+    float   scale[3];              /* scale_factor                     */
+} svr_lod_state;
+
+/* == u_material uniform (_material.py:6-24 + inherited VolumeMipMaterial
+ * clim/gamma/opacity). colors is n x vec4 (h, s, v, pad) as the reference
+ * pads it (_material.py:139-159). */
+typedef struct svr_material {
+    float    clim[2];
+    float    gamma;
+    float    opacity;
+    float    lmip_threshold;
+    float    lmip_fall_off;
+    int32_t  lmip_max_samples;     /* i32 in the reference (_material.py:10-11) */
+    float    fog_density;
+    float    fog_color[3];
+    uint32_t color_count;
+    const float* colors;           /* host pointer, color_count * 4 floats */
+    int32_t  colorspace_srgb;      /* 1: apply srgb2physical (raycast.wgsl:71-72; texture default) */
+} svr_material;
+
+/* == the six mat4 of u_stdinfo / u_wobject that the shaders read
+ * (vs_main.wgsl:18-22, fs_main.wgsl:62-63) + u_wobject.volume_dimensions
+ * (_wobject.py:14-17).  Matrices are COLUMN-MAJOR float[16] (m[c*4+r]) like
+ * WGSL mat4x4<f32>. */
+typedef struct svr_camera {
+    float world[16];
+    float world_inv[16];
+    float cam[16];
+    float cam_inv[16];
+    float proj[16];
+    float proj_inv[16];
+    float volume_dimensions[3];    /* shader order (x, y, z) */
+} svr_camera;
+
+/* Which pixels of the full frame this call renders.  Output row r (0..out_h)
+ * and column c (0..out_w) map to the frame pixel
+ *     x = x0 + c
+ *     y = y0 + (r / band_h) * band_pitch + (r % band_h)
+ * A plain tile is band_h = out_h (band_pitch unused).  Interleaved stripes
+ * for multi-GPU load balance use band_h = stripe height and
+ * band_pitch = stripe height * number of ranks.  Rows with y >= frame_h are
+ * padding: written as "discarded". */
+typedef struct svr_frame {
+    int32_t frame_w, frame_h;      /* full frame: NDC uses these (vs_main.wgsl:19) */
+    int32_t x0, y0;
+    int32_t out_w, out_h;
+    int32_t band_h, band_pitch;
+} svr_frame;
+
+/* pixel classification written to svr_outputs.flags */
+#define SVR_PIX_DISCARD 0   /* no back-face fragment, or nsteps < 1 (fs_main.wgsl:44) */
+#define SVR_PIX_MISS    1   /* fragment ran, no significant value (fs_main.wgsl:93-98) */
+#define SVR_PIX_HIT     2   /* fragment ran, LMIP found a local maximum (fs_main.wgsl:56-87) */
+
+/* DEVICE pointers, caller-allocated, each out_h*out_w elements (rgba: x4).
+ * rgba is the fragment's out.color before blending (fs_main.wgsl:86,95);
+ * discarded pixels get (0,0,0,0).  Any pointer except rgba may be NULL. */
+typedef struct svr_outputs {
+    float*    rgba;
+    float*    depth;               /* out.depth (fs_main.wgsl:72,97) */
+    uint32_t* label;               /* render_out.segmentation (raycast.wgsl:81) */
+    uint8_t*  flags;               /* SVR_PIX_* */
+    uint32_t* steps;               /* executed iterations of raycast.wgsl:29-62 per pixel
+                                      (instrumented build of the kernel; NULL in production) */
+} svr_outputs;
+
+typedef struct svr_ctx svr_ctx;
+
+/* ---- lifecycle: replaces WrappingBuffer.__init__ texture/uniform creation
+ * (_wrapping_buffer.py:47-70) for all LODs of one SubVolume (_wobject.py:72-91) */
+int  svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out_ctx);
+int  svr_destroy(svr_ctx* ctx);
+const char* svr_last_error(void);
+int  svr_abi_version(void);
+
+/* ---- uniforms */
+/* _current_logical_roi_in_pixels setter + scale_factor setter
+ * (_wrapping_buffer.py:77-97,105-116).  Takes effect for renders enqueued
+ * after the call. */
+int  svr_set_lod_state(svr_ctx* ctx, int lod, const svr_lod_state* st);
+int  svr_get_lod_state(svr_ctx* ctx, int lod, svr_lod_state* st);
+/* SubVolumeMaterial uniform block (_material.py:60-159) */
+int  svr_set_material(svr_ctx* ctx, const svr_material* m);
+
+/* ---- texture upload: replaces texture.data[dst] = np.array(src, f32|u32);
+ * texture.update_range(...) for BOTH textures (_wrapping_buffer.py:325-335).
+ * dst_off/shape: ring voxels, shader order; must lie inside the ring.
+ * density/labels: HOST pointers to element (0,0,0) of the source block;
+ * strides in BYTES per (x, y, z) step.  Conversion is numpy's cast (to f32 /
+ * to u32 with wrap-around).  The copy is staged through pinned memory and
+ * enqueued on the context's upload stream; the call returns once the source
+ * has been consumed (source may be freed), not when the device copy is done.
+ * Either source may be NULL to leave that texture untouched. */
+int  svr_upload_region(svr_ctx* ctx, int lod,
+                       const int32_t dst_off[3], const int32_t shape[3],
+                       const void* density, int density_dtype, const int64_t density_strides[3],
+                       const void* labels,  int labels_dtype,  const int64_t labels_strides[3]);
+/* same, but the sources are DEVICE pointers (backing volume resident in HBM) */
+int  svr_upload_region_device(svr_ctx* ctx, int lod,
+                       const int32_t dst_off[3], const int32_t shape[3],
+                       const void* density, int density_dtype, const int64_t density_strides[3],
+                       const void* labels,  int labels_dtype,  const int64_t labels_strides[3]);
+/* Make everything uploaded so far visible to subsequent renders: the render
+ * stream waits (device-side) on an event recorded on the upload stream.  The
+ * reference has no equivalent: pygfx flushes update_range uploads before the
+ * next draw on the same queue (FUTURE.md:47-58). */
+int  svr_publish_uploads(svr_ctx* ctx);
+
+/* ---- readback of a ring region into packed host arrays (shader-order
+ * shape, x fastest): the texture.data numpy mirror the reference's tests read
+ * (tests/wrapping_buffer/test_load_logical_roi.py:5-76).  Synchronous. */
+int  svr_read_region(svr_ctx* ctx, int lod, const int32_t off[3], const int32_t shape[3],
+                     float* density_out, uint32_t* labels_out);
+/* zero both textures of one LOD (fresh WrappingBuffer state) */
+int  svr_clear_lod(svr_ctx* ctx, int lod);
+
+/* ---- the draw: replaces renderer.render(scene, camera) for the
+ * (SubVolume, SubVolumeMaterial) pair — vs_main.wgsl:6-50 + fs_main.wgsl:4-101
+ * + raycast.wgsl:11-88 + sample_vol.wgsl + hsv_selection.wgsl.
+ * Enqueued on `stream` (a hipStream_t passed as void*; NULL = the context's
+ * own render stream).  Asynchronous. */
+int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
+                const svr_outputs* out, void* stream);
+/* kernel variant selector for A/B measurement: 0 = default (tuned),
+ * 1 = straightforward one-thread-per-pixel global-memory march */
+int  svr_set_variant(svr_ctx* ctx, int variant);
+
+/* ---- multi-GPU helper: scatter a rank-major gathered stripe buffer back
+ * into a full frame (device pointers).  gathered holds nranks blocks of
+ * out_h*out_w*elem_bytes each, laid out by svr_frame with x0 = 0,
+ * y0 = rank*band_h, band_pitch = band_h*nranks. */
+int  svr_untile_stripes(svr_ctx* ctx, const void* gathered, void* frame_out,
+                        int frame_w, int frame_h, int band_h, int nranks,
+                        int out_h, int elem_bytes, void* stream);
+
+/* ---- sync */
+int  svr_sync(svr_ctx* ctx);                 /* both streams idle */
+int  svr_sync_uploads(svr_ctx* ctx);         /* upload stream idle */
+/* raw device pointers of one LOD's ring textures (for diagnostics / RCCL) */
+int  svr_lod_device_ptrs(svr_ctx* ctx, int lod, void** density, void** labels);
+
+/* timing helper: run `iters` back-to-back renders on the context's render
+ * stream bracketed by HIP events on that same stream; returns the average
+ * kernel time in milliseconds (used by bench.py's roofline block). */
+int  svr_time_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
+                     const svr_outputs* out, int iters, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_H */

@@ -1,0 +1,283 @@
+"""``SubVolume`` — the multi-LOD volume object and its draw call.
+
+Mirror of the reference's ``SubVolume(gfx.Volume)``
+(``src/sub_volume/_wobject.py:13-226``): same constructor, validation errors,
+attributes and ``center_on_position()``.  The reference is drawn by pygfx's
+``renderer.render(scene, camera)`` through the plugin in ``_shader.py``; pygfx does
+not exist on the target, so the draw is the explicit :meth:`SubVolume.render`,
+which hands the camera matrices and the frame region to ``svr_render``
+(include/svr.h) — one HIP kernel launch for vs_main + fs_main + raycast.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+from ._geometry import Coordinate, Roi
+from ._material import SubVolumeMaterial
+from ._transform import _HasWorld
+from ._wrapping_buffer import DeviceRings, WrappingBuffer
+
+
+@dataclass
+class FrameRegion:
+    """Which pixels of the full frame one call renders (``svr_frame``)."""
+
+    x0: int = 0
+    y0: int = 0
+    out_w: int = 0
+    out_h: int = 0
+    band_h: int = 0       # 0: one contiguous tile
+    band_pitch: int = 0
+
+    @staticmethod
+    def full(width: int, height: int) -> "FrameRegion":
+        return FrameRegion(0, 0, width, height, height, height)
+
+    @staticmethod
+    def tile(x0: int, y0: int, w: int, h: int) -> "FrameRegion":
+        return FrameRegion(x0, y0, w, h, h, h)
+
+    @staticmethod
+    def stripes(width: int, height: int, rank: int, nranks: int, band_h: int = 8) -> "FrameRegion":
+        """Rows dealt to ranks round-robin in bands of ``band_h`` rows (padded to equal size)."""
+        nbands = -(-height // band_h)
+        per_rank = -(-nbands // nranks)
+        return FrameRegion(0, rank * band_h, width, per_rank * band_h, band_h, band_h * nranks)
+
+
+@dataclass
+class RenderResult:
+    """Device tensors written by one draw (fragment outputs before blending)."""
+
+    rgba: "object"            # torch f32 [h, w, 4]   out.color   (fs_main.wgsl:86,95)
+    depth: "object | None"    # torch f32 [h, w]      out.depth   (fs_main.wgsl:72,97)
+    label: "object | None"    # torch i32 [h, w]      bit pattern of the u32 label (raycast.wgsl:81)
+    flags: "object | None"    # torch u8  [h, w]      0 discard / 1 miss / 2 hit
+    steps: "object | None"    # torch i32 [h, w]      executed march iterations (instrumented)
+
+    def label_numpy(self) -> np.ndarray:
+        return self.label.cpu().numpy().view(np.uint32)
+
+
+class SubVolume(_HasWorld):
+    material: SubVolumeMaterial
+
+    def __init__(
+        self,
+        material: SubVolumeMaterial,
+        data_segmentation_pairs,
+        buffer_shape_in_chunks,
+        chunk_shape_in_pixels=None,
+        *,
+        device: int | None = None,
+    ):
+        super().__init__()
+        base_data = data_segmentation_pairs[0][0]
+        num_scales = len(data_segmentation_pairs)
+
+        # one shape for all scales (tuple) or one per scale (list) — _wobject.py:34-63
+        if isinstance(buffer_shape_in_chunks, tuple):
+            buffer_shapes = [buffer_shape_in_chunks] * num_scales
+        else:
+            buffer_shapes = buffer_shape_in_chunks
+            if len(buffer_shapes) != num_scales:
+                raise ValueError(
+                    f"buffer_shape_in_chunks list length ({len(buffer_shapes)}) must match number of scales ({num_scales})"
+                )
+        if chunk_shape_in_pixels is None:
+            if hasattr(base_data, "chunks"):
+                chunk_shapes = [base_data.chunks] * num_scales
+            else:
+                raise ValueError(
+                    "if chunk_shape_in_pixels is not provided, base data must have a 'chunks' attribute"
+                )
+        elif isinstance(chunk_shape_in_pixels, tuple):
+            chunk_shapes = [chunk_shape_in_pixels] * num_scales
+        else:
+            chunk_shapes = chunk_shape_in_pixels
+            if len(chunk_shapes) != num_scales:
+                raise ValueError(
+                    f"chunk_shape_in_pixels list length ({len(chunk_shapes)}) must match number of scales ({num_scales})"
+                )
+        for i, (scale_data, _) in enumerate(data_segmentation_pairs):
+            if len(chunk_shapes[i]) != scale_data.ndim:
+                raise ValueError(f"chunk_shape_in_pixels[{i}] length must match data dimensions")
+        if num_scales > N.SVR_MAX_LODS:
+            raise ValueError(f"at most {N.SVR_MAX_LODS} scales are supported")
+
+        self.material = material
+        # all LODs share one device context (one svr_ctx); created lazily on first device use
+        self._rings = DeviceRings(
+            [tuple(Coordinate(b) * Coordinate(c)) for b, c in zip(buffer_shapes, chunk_shapes)],
+            device=device,
+        )
+        self.wrapping_buffers: list[WrappingBuffer] = []
+        for i, (scale_data, scale_segmentations) in enumerate(data_segmentation_pairs):
+            # same-sized voxels: lower resolutions sample at scaled-down coordinates (_wobject.py:79-81)
+            scale_factor = tuple(float(scale_data.shape[j]) / float(base_data.shape[j]) for j in range(3))
+            self.wrapping_buffers.append(
+                WrappingBuffer(
+                    backing_data=scale_data,
+                    segmentations=scale_segmentations,
+                    shape_in_chunks=buffer_shapes[i],
+                    chunk_shape_in_pixels=chunk_shapes[i],
+                    scale_factor=scale_factor,
+                    _rings=self._rings,
+                    _lod=i,
+                )
+            )
+        self._volume_dimensions = np.zeros(3, np.float32)
+        self.volume_dimensions = base_data.shape
+        self._material_version_pushed = -1
+        self._out_cache = {}
+
+    # -- _wobject.py:103-133 ---------------------------------------------------
+    @property
+    def volume_dimensions(self):
+        """The dimensions of the volume in pixels, numpy axis order."""
+        return tuple(self._volume_dimensions[::-1])
+
+    @volume_dimensions.setter
+    def volume_dimensions(self, value):
+        # stored reversed = shader order, like the reference's uniform (_wobject.py:121-123)
+        self._volume_dimensions = np.array(tuple(value)[::-1], dtype=np.float32)
+
+    @property
+    def textures(self):
+        """All scale level textures."""
+        return [b.texture for b in self.wrapping_buffers]
+
+    @property
+    def segmentations_textures(self):
+        """All scale level segmentation textures."""
+        return [b.segmentations_texture for b in self.wrapping_buffers]
+
+    # -- _wobject.py:135-208 ---------------------------------------------------
+    def center_on_position(self, position, sizes=None):
+        """Center every LOD's ring window on a world position (x, y, z).
+
+        ``sizes``: window size per scale in that scale's voxels (numpy order).  By
+        default one chunk less than the ring per axis, so that growing the window
+        to the chunk grid can never exceed the ring (_wobject.py:151-177).
+        """
+        if sizes is None:
+            sizes = [
+                (b.shape_in_chunks - Coordinate(1, 1, 1)) * b.chunk_shape_in_pixels
+                for b in self.wrapping_buffers
+            ]
+        if len(sizes) != len(self.wrapping_buffers):
+            raise ValueError(
+                f"sizes list length ({len(sizes)}) must match number of scales ({len(self.wrapping_buffers)})"
+            )
+        # world -> data space; the matrix works in shader order, so reverse to numpy order
+        p = (self.world.inverse_matrix @ np.array([*position, 1.0]))[:3][::-1]
+        for size, buffer in zip(sizes, self.wrapping_buffers):
+            offset = tuple(int(c * f - s // 2) for c, s, f in zip(p, size, buffer.scale_factor))
+            roi = Roi(offset, size)
+            if buffer.can_load_logical_roi(roi):
+                buffer.load_logical_roi(roi)
+
+    # -- the draw --------------------------------------------------------------
+    def _push_material(self):
+        m = self.material
+        if self._material_version_pushed == m._version:
+            return
+        u = m._u
+        cm = N.Material()
+        cm.clim[:] = [float(u["clim"][0]), float(u["clim"][1])]
+        cm.gamma = float(u["gamma"])
+        cm.opacity = float(u["opacity"])
+        cm.lmip_threshold = float(u["lmip_threshold"])
+        cm.lmip_fall_off = float(u["lmip_fall_off"])
+        cm.lmip_max_samples = int(u["lmip_max_samples"])
+        cm.fog_density = float(u["fog_density"])
+        cm.fog_color[:] = [float(v) for v in u["fog_color"]]
+        colors = np.ascontiguousarray(u["colors"], np.float32)
+        cm.color_count = int(colors.shape[0])
+        cm.colors = colors.ctypes.data_as(C.POINTER(C.c_float))
+        # _shader.py:68: colorspace of the first texture; 'srgb' selects srgb2physical
+        cm.colorspace_srgb = 1 if self.textures[0].colorspace == "srgb" else 0
+        N.check(N.lib().svr_set_material(self._rings.handle, C.byref(cm)), "svr_set_material")
+        self._material_version_pushed = m._version
+
+    def camera_block(self, camera) -> "N.Camera":
+        """The uniforms vs_main/fs_main read, as ``svr_camera``."""
+        cb = N.Camera()
+        cb.world = N.mat_to_c(self.world.matrix)
+        cb.world_inv = N.mat_to_c(self.world.inverse_matrix)
+        cb.cam = N.mat_to_c(camera.view_matrix)
+        cb.cam_inv = N.mat_to_c(camera.camera_matrix)
+        cb.proj = N.mat_to_c(camera.projection_matrix)
+        cb.proj_inv = N.mat_to_c(camera.projection_matrix_inverse)
+        cb.volume_dimensions[:] = [float(v) for v in self._volume_dimensions]
+        return cb
+
+    def frame_block(self, width: int, height: int, region: FrameRegion | None) -> "N.Frame":
+        r = region or FrameRegion.full(width, height)
+        fb = N.Frame()
+        fb.frame_w, fb.frame_h = int(width), int(height)
+        fb.x0, fb.y0, fb.out_w, fb.out_h = int(r.x0), int(r.y0), int(r.out_w), int(r.out_h)
+        fb.band_h = int(r.band_h or r.out_h)
+        fb.band_pitch = int(r.band_pitch or r.out_h)
+        return fb
+
+    def _outputs(self, h, w, want_steps):
+        import torch
+
+        key = (h, w, bool(want_steps))
+        res = self._out_cache.get(key)
+        if res is None:
+            dev = torch.device("cuda", self._rings.device if self._rings.device is not None else torch.cuda.current_device())
+            res = RenderResult(
+                rgba=torch.empty((h, w, 4), dtype=torch.float32, device=dev),
+                depth=torch.empty((h, w), dtype=torch.float32, device=dev),
+                label=torch.empty((h, w), dtype=torch.int32, device=dev),
+                flags=torch.empty((h, w), dtype=torch.uint8, device=dev),
+                steps=torch.empty((h, w), dtype=torch.int32, device=dev) if want_steps else None,
+            )
+            self._out_cache = {key: res}
+        return res
+
+    def prepare(self):
+        """Push pending uniforms (material, per-LOD ROI/scale) to the device."""
+        handle = self._rings.handle  # creates the context on first use
+        self._push_material()
+        for b in self.wrapping_buffers:
+            b._push_state()
+        return handle
+
+    def render(self, camera, width: int, height: int, *, region: FrameRegion | None = None,
+               count_steps: bool = False, out: RenderResult | None = None, stream=None) -> RenderResult:
+        """Draw this volume as seen by ``camera`` into device tensors.
+
+        Replaces ``renderer.render(scene, camera)`` for the (SubVolume,
+        SubVolumeMaterial) pair (scripts/multi_scale.py:76-80).  Asynchronous:
+        the kernel is enqueued on the current torch stream.
+        """
+        import torch
+
+        handle = self.prepare()
+        cb = self.camera_block(camera)
+        fb = self.frame_block(width, height, region)
+        res = out or self._outputs(fb.out_h, fb.out_w, count_steps)
+        ob = N.Outputs()
+        ob.rgba = res.rgba.data_ptr()
+        ob.depth = res.depth.data_ptr() if res.depth is not None else None
+        ob.label = res.label.data_ptr() if res.label is not None else None
+        ob.flags = res.flags.data_ptr() if res.flags is not None else None
+        ob.steps = res.steps.data_ptr() if (count_steps and res.steps is not None) else None
+        if stream is None:
+            stream = torch.cuda.current_stream(self._rings.device).cuda_stream
+        N.check(
+            N.lib().svr_render(handle, C.byref(cb), C.byref(fb), C.byref(ob), C.c_void_p(stream)),
+            "svr_render",
+        )
+        return res
+
+    def synchronize(self):
+        N.check(N.lib().svr_sync(self._rings.handle), "svr_sync")

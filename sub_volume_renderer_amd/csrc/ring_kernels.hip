@@ -1,0 +1,165 @@
+// Ring-buffer data movement kernels for gfx950: dtype-converting scatter of a
+// chunk slab into the ring textures (the device half of
+// `texture.data[dst] = np.array(src, f32|u32)`, _wrapping_buffer.py:325-335),
+// the read-back gather, and the stripe un-tiler used after the RCCL gather.
+// All three are pure HBM streaming; rows (x) are the contiguous axis.
+#include "svr_internal.h"
+
+size_t svr_dtype_size(int dtype) {
+    switch (dtype) {
+        case SVR_U8: case SVR_I8: return 1;
+        case SVR_U16: case SVR_I16: return 2;
+        case SVR_U32: case SVR_I32: case SVR_F32: return 4;
+        case SVR_U64: case SVR_I64: case SVR_F64: return 8;
+        default: return 0;
+    }
+}
+
+namespace {
+
+// numpy cast semantics: any -> float32
+__device__ __forceinline__ float load_as_f32(const char* p, int dtype) {
+    switch (dtype) {
+        case SVR_U8:  return (float)*reinterpret_cast<const uint8_t*>(p);
+        case SVR_U16: return (float)*reinterpret_cast<const uint16_t*>(p);
+        case SVR_U32: return (float)*reinterpret_cast<const uint32_t*>(p);
+        case SVR_U64: return (float)*reinterpret_cast<const uint64_t*>(p);
+        case SVR_I8:  return (float)*reinterpret_cast<const int8_t*>(p);
+        case SVR_I16: return (float)*reinterpret_cast<const int16_t*>(p);
+        case SVR_I32: return (float)*reinterpret_cast<const int32_t*>(p);
+        case SVR_I64: return (float)*reinterpret_cast<const int64_t*>(p);
+        case SVR_F32: return *reinterpret_cast<const float*>(p);
+        default:      return (float)*reinterpret_cast<const double*>(p);
+    }
+}
+
+// numpy cast semantics: integer -> uint32 wraps modulo 2^32; float -> uint32
+// truncates toward zero (values outside the range are undefined in numpy too)
+__device__ __forceinline__ uint32_t load_as_u32(const char* p, int dtype) {
+    switch (dtype) {
+        case SVR_U8:  return (uint32_t)*reinterpret_cast<const uint8_t*>(p);
+        case SVR_U16: return (uint32_t)*reinterpret_cast<const uint16_t*>(p);
+        case SVR_U32: return *reinterpret_cast<const uint32_t*>(p);
+        case SVR_U64: return (uint32_t)*reinterpret_cast<const uint64_t*>(p);
+        case SVR_I8:  return (uint32_t)(int32_t)*reinterpret_cast<const int8_t*>(p);
+        case SVR_I16: return (uint32_t)(int32_t)*reinterpret_cast<const int16_t*>(p);
+        case SVR_I32: return (uint32_t)*reinterpret_cast<const int32_t*>(p);
+        case SVR_I64: return (uint32_t)*reinterpret_cast<const int64_t*>(p);
+        case SVR_F32: return (uint32_t)(int64_t)*reinterpret_cast<const float*>(p);
+        default:      return (uint32_t)(int64_t)*reinterpret_cast<const double*>(p);
+    }
+}
+
+// One thread per voxel, x fastest: loads and stores of a wave are contiguous
+// runs of the slab row / ring row.
+__global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
+    const size_t n = (size_t)a.shape[0] * (size_t)a.shape[1] * (size_t)a.shape[2];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t x = (uint32_t)(i % (size_t)a.shape[0]);
+        const size_t   q = i / (size_t)a.shape[0];
+        const uint32_t y = (uint32_t)(q % (size_t)a.shape[1]);
+        const uint32_t z = (uint32_t)(q / (size_t)a.shape[1]);
+        const size_t dst = ((size_t)(z + a.dst_off[2]) * (size_t)a.ring[1] + (size_t)(y + a.dst_off[1])) *
+                               (size_t)a.ring[0] + (size_t)(x + a.dst_off[0]);
+        if (a.src_density) {
+            const char* p = static_cast<const char*>(a.src_density) +
+                            (int64_t)x * a.dstride[0] + (int64_t)y * a.dstride[1] + (int64_t)z * a.dstride[2];
+            a.ring_density[dst] = load_as_f32(p, a.density_dtype);
+        }
+        if (a.src_labels) {
+            const char* p = static_cast<const char*>(a.src_labels) +
+                            (int64_t)x * a.lstride[0] + (int64_t)y * a.lstride[1] + (int64_t)z * a.lstride[2];
+            a.ring_labels[dst] = load_as_u32(p, a.labels_dtype);
+        }
+    }
+}
+
+struct GatherArgs {
+    const float* ring_density; const uint32_t* ring_labels;
+    int32_t ring[3], off[3], shape[3];
+    float* out_density; uint32_t* out_labels;
+};
+
+__global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
+    const size_t n = (size_t)a.shape[0] * (size_t)a.shape[1] * (size_t)a.shape[2];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t x = (uint32_t)(i % (size_t)a.shape[0]);
+        const size_t   q = i / (size_t)a.shape[0];
+        const uint32_t y = (uint32_t)(q % (size_t)a.shape[1]);
+        const uint32_t z = (uint32_t)(q / (size_t)a.shape[1]);
+        const size_t src = ((size_t)(z + a.off[2]) * (size_t)a.ring[1] + (size_t)(y + a.off[1])) *
+                               (size_t)a.ring[0] + (size_t)(x + a.off[0]);
+        if (a.out_density) a.out_density[i] = a.ring_density[src];
+        if (a.out_labels)  a.out_labels[i]  = a.ring_labels[src];
+    }
+}
+
+// gathered: [nranks][out_h][frame_w] elements of elem_bytes (4 or 16); rank k's
+// row r is frame row (r / band_h) * band_h * nranks + k * band_h + r % band_h.
+template <typename T>
+__global__ __launch_bounds__(256) void untile_kernel(const T* gathered, T* frame, int frame_w, int frame_h,
+                                                     int band_h, int nranks, int out_h) {
+    const size_t n = (size_t)frame_w * (size_t)frame_h;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int x = (int)(i % (size_t)frame_w);
+        const int y = (int)(i / (size_t)frame_w);
+        const int band = y / band_h, in_band = y % band_h;
+        const int rank = band % nranks, k = band / nranks;
+        const size_t r = (size_t)k * band_h + in_band;
+        frame[i] = gathered[((size_t)rank * out_h + r) * (size_t)frame_w + x];
+    }
+}
+
+inline int grid_for(size_t n) {
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = 256 * 8;          // 256 CUs x 8 blocks, grid-stride the rest
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream) {
+    const size_t n = (size_t)a.shape[0] * (size_t)a.shape[1] * (size_t)a.shape[2];
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t svr_launch_gather(const float* ring_density, const uint32_t* ring_labels, const int32_t ring[3],
+                             const int32_t off[3], const int32_t shape[3],
+                             float* out_density, uint32_t* out_labels, hipStream_t stream) {
+    GatherArgs a;
+    a.ring_density = ring_density; a.ring_labels = ring_labels;
+    for (int i = 0; i < 3; ++i) { a.ring[i] = ring[i]; a.off[i] = off[i]; a.shape[i] = shape[i]; }
+    a.out_density = out_density; a.out_labels = out_labels;
+    const size_t n = (size_t)shape[0] * (size_t)shape[1] * (size_t)shape[2];
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,
+                             int band_h, int nranks, int out_h, int elem_bytes, hipStream_t stream) {
+    const size_t n = (size_t)frame_w * (size_t)frame_h;
+    if (n == 0) return hipSuccess;
+    if (elem_bytes == 16)
+        hipLaunchKernelGGL((untile_kernel<float4>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const float4*>(gathered), static_cast<float4*>(frame_out),
+                           frame_w, frame_h, band_h, nranks, out_h);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL((untile_kernel<uint32_t>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const uint32_t*>(gathered), static_cast<uint32_t*>(frame_out),
+                           frame_w, frame_h, band_h, nranks, out_h);
+    else if (elem_bytes == 1)
+        hipLaunchKernelGGL((untile_kernel<uint8_t>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(gathered), static_cast<uint8_t*>(frame_out),
+                           frame_w, frame_h, band_h, nranks, out_h);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -1,0 +1,461 @@
+// Host side of the C ABI declared in include/svr.h.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "svr_internal.h"
+
+static thread_local std::string g_err;
+void svr_set_error(const std::string& msg) { g_err = msg; }
+
+#define SVR_REQUIRE(cond, msg)                    \
+    do {                                          \
+        if (!(cond)) {                            \
+            svr_set_error(msg);                   \
+            return SVR_ERR_INVALID;               \
+        }                                         \
+    } while (0)
+
+namespace {
+
+// f32 matrix helpers in the contract's operation order (see oracle/lmip_oracle.c header)
+void mat_vec4(const float* m, const float* v, float* r) {
+    for (int i = 0; i < 4; ++i) r[i] = ((m[0 + i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2]) + m[12 + i] * v[3];
+}
+void mat_mul4(const float* a, const float* b, float* out) {
+    for (int c = 0; c < 4; ++c) mat_vec4(a, b + 4 * c, out + 4 * c);
+}
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) { ok = hipSetDevice(dev) == hipSuccess; }
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int floor_div(int a, int b) { int q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; }
+
+}  // namespace
+
+extern "C" {
+
+const char* svr_last_error(void) { return g_err.c_str(); }
+int svr_abi_version(void) { return SVR_ABI_VERSION; }
+
+int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out_ctx) {
+    SVR_REQUIRE(out_ctx && lods, "svr_create: null argument");
+    SVR_REQUIRE(num_lods >= 1 && num_lods <= SVR_MAX_LODS, "svr_create: num_lods out of range");
+    int ndev = 0;
+    SVR_HIP_TRY(hipGetDeviceCount(&ndev));
+    SVR_REQUIRE(device >= 0 && device < ndev, "svr_create: no such HIP device (is a GPU visible?)");
+    for (int l = 0; l < num_lods; ++l)
+        for (int a = 0; a < 3; ++a)
+            SVR_REQUIRE(lods[l].ring_dims[a] >= 1 && lods[l].ring_dims[a] < (1 << 24),
+                        "svr_create: ring extent must be in [1, 2^24)");
+    DeviceGuard guard(device);
+    svr_ctx* c = new svr_ctx();
+    c->device = device; c->num_lods = num_lods;
+    c->render_stream = nullptr; c->upload_stream = nullptr; c->uploads_published = nullptr;
+    c->have_published = false; c->colors_dev = nullptr; c->colors_cap = 0; c->material_set = false;
+    c->variant = 0; c->slot_bytes = 0; c->next_slot = 0; c->ev_a = c->ev_b = nullptr;
+    c->render_done = nullptr; c->render_pending = false;
+    for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
+    for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
+
+    auto fail = [&](int code) { svr_destroy(c); return code; };
+    if (hipStreamCreateWithFlags(&c->render_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->uploads_published, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
+        svr_set_error("svr_create: stream/event creation failed");
+        return fail(SVR_ERR_HIP);
+    }
+    for (int l = 0; l < num_lods; ++l) {
+        LodStorage& L = c->lod[l];
+        for (int a = 0; a < 3; ++a) L.ring[a] = lods[l].ring_dims[a];
+        L.voxels = (size_t)L.ring[0] * (size_t)L.ring[1] * (size_t)L.ring[2];
+        memset(&L.state, 0, sizeof(L.state));
+        L.state.scale[0] = L.state.scale[1] = L.state.scale[2] = 1.0f;
+        if (hipMalloc((void**)&L.density, L.voxels * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&L.labels, L.voxels * sizeof(uint32_t)) != hipSuccess) {
+            svr_set_error("svr_create: out of device memory for ring textures");
+            return fail(SVR_ERR_NOMEM);
+        }
+        // zero-initialised textures (_wrapping_buffer.py:50-59)
+        if (hipMemsetAsync(L.density, 0, L.voxels * sizeof(float), c->upload_stream) != hipSuccess ||
+            hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream) != hipSuccess) {
+            svr_set_error("svr_create: memset failed");
+            return fail(SVR_ERR_HIP);
+        }
+    }
+    if (hipEventRecord(c->uploads_published, c->upload_stream) != hipSuccess) return fail(SVR_ERR_HIP);
+    c->have_published = true;
+    *out_ctx = c;
+    return SVR_OK;
+}
+
+int svr_destroy(svr_ctx* c) {
+    if (!c) return SVR_OK;
+    DeviceGuard guard(c->device);
+    if (c->render_stream) (void)hipStreamSynchronize(c->render_stream);
+    if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
+    for (int l = 0; l < SVR_MAX_LODS; ++l) {
+        if (c->lod[l].density) (void)hipFree(c->lod[l].density);
+        if (c->lod[l].labels) (void)hipFree(c->lod[l].labels);
+    }
+    for (auto& s : c->slot) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (c->colors_dev) (void)hipFree(c->colors_dev);
+    if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
+    if (c->render_done) (void)hipEventDestroy(c->render_done);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->render_stream) (void)hipStreamDestroy(c->render_stream);
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
+    delete c;
+    return SVR_OK;
+}
+
+int svr_set_lod_state(svr_ctx* c, int lod, const svr_lod_state* st) {
+    SVR_REQUIRE(c && st, "svr_set_lod_state: null argument");
+    SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_set_lod_state: lod out of range");
+    for (int a = 0; a < 3; ++a) {
+        SVR_REQUIRE(st->offset[a] >= 0 && st->shape[a] >= 0, "svr_set_lod_state: negative offset/shape");
+        SVR_REQUIRE(st->shape[a] <= c->lod[lod].ring[a], "svr_set_lod_state: ROI larger than the ring");
+    }
+    c->lod[lod].state = *st;
+    return SVR_OK;
+}
+
+int svr_get_lod_state(svr_ctx* c, int lod, svr_lod_state* st) {
+    SVR_REQUIRE(c && st, "svr_get_lod_state: null argument");
+    SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_get_lod_state: lod out of range");
+    *st = c->lod[lod].state;
+    return SVR_OK;
+}
+
+int svr_set_material(svr_ctx* c, const svr_material* m) {
+    SVR_REQUIRE(c && m, "svr_set_material: null argument");
+    SVR_REQUIRE(m->color_count >= 1 && m->colors, "svr_set_material: at least one colour is required");
+    DeviceGuard guard(c->device);
+    const size_t ncol = (size_t)m->color_count * 4;
+    const bool same_colors = c->material_set && c->colors_host.size() == ncol &&
+                             memcmp(c->colors_host.data(), m->colors, ncol * sizeof(float)) == 0;
+    c->material = *m;
+    c->material.colors = nullptr;
+    if (same_colors) return SVR_OK;
+    c->colors_host.assign(m->colors, m->colors + ncol);
+    if (m->color_count > c->colors_cap) {
+        if (c->colors_dev) { SVR_HIP_TRY(hipStreamSynchronize(c->render_stream)); (void)hipFree(c->colors_dev); c->colors_dev = nullptr; }
+        uint32_t cap = std::max<uint32_t>(256u, m->color_count);
+        if (hipMalloc((void**)&c->colors_dev, (size_t)cap * 4 * sizeof(float)) != hipSuccess) {
+            svr_set_error("svr_set_material: out of device memory"); return SVR_ERR_NOMEM;
+        }
+        c->colors_cap = cap;
+    }
+    // synchronous small copy: ordered before any later launch on any stream
+    SVR_HIP_TRY(hipDeviceSynchronize());
+    SVR_HIP_TRY(hipMemcpy(c->colors_dev, c->colors_host.data(), c->colors_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->material_set = true;
+    return SVR_OK;
+}
+
+int svr_set_variant(svr_ctx* c, int variant) {
+    SVR_REQUIRE(c, "svr_set_variant: null ctx");
+    c->variant = variant;
+    return SVR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// uploads
+// ---------------------------------------------------------------------------
+static int check_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t shape[3], const char* who) {
+    if (!c || !off || !shape) { svr_set_error(std::string(who) + ": null argument"); return SVR_ERR_INVALID; }
+    if (lod < 0 || lod >= c->num_lods) { svr_set_error(std::string(who) + ": lod out of range"); return SVR_ERR_INVALID; }
+    for (int a = 0; a < 3; ++a) {
+        if (off[a] < 0 || shape[a] < 0 || (int64_t)off[a] + shape[a] > c->lod[lod].ring[a]) {
+            svr_set_error(std::string(who) + ": region outside the ring");
+            return SVR_ERR_RANGE;
+        }
+    }
+    return SVR_OK;
+}
+
+// A render enqueued earlier may still be reading the ring slots an upload is
+// about to overwrite: order the upload stream behind it (the reference gets this
+// ordering from running everything on one queue).
+static int uploads_after_render(svr_ctx* c) {
+    if (c->render_pending) {
+        SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->render_done, 0));
+        c->render_pending = false;
+    }
+    return SVR_OK;
+}
+
+static int ensure_staging(svr_ctx* c) {
+    if (c->slot_bytes) return SVR_OK;
+    const size_t bytes = (size_t)48 << 20;   // per slot; 3 slots -> 144 MiB pinned
+    for (auto& s : c->slot) {
+        if (hipHostMalloc(&s.host, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.dev, bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+            svr_set_error("staging allocation failed");
+            return SVR_ERR_NOMEM;
+        }
+        s.used = false;
+    }
+    c->slot_bytes = bytes;
+    return SVR_OK;
+}
+
+// copy rows [z0,z1) of a strided host block into a packed buffer (x fastest)
+static void pack_rows(const char* src, size_t es, const int64_t st[3], const int32_t shape[3], int z0, int z1, char* dst) {
+    const size_t row = (size_t)shape[0] * es;
+    for (int z = z0; z < z1; ++z)
+        for (int y = 0; y < shape[1]; ++y) {
+            const char* s = src + (int64_t)z * st[2] + (int64_t)y * st[1];
+            if (st[0] == (int64_t)es) memcpy(dst, s, row);
+            else for (int x = 0; x < shape[0]; ++x) memcpy(dst + (size_t)x * es, s + (int64_t)x * st[0], es);
+            dst += row;
+        }
+}
+
+int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32_t shape[3],
+                      const void* density, int density_dtype, const int64_t density_strides[3],
+                      const void* labels, int labels_dtype, const int64_t labels_strides[3]) {
+    int rc = check_region(c, lod, dst_off, shape, "svr_upload_region");
+    if (rc) return rc;
+    const size_t des = density ? svr_dtype_size(density_dtype) : 0;
+    const size_t les = labels ? svr_dtype_size(labels_dtype) : 0;
+    SVR_REQUIRE(!density || (des && density_strides), "svr_upload_region: bad density dtype/strides");
+    SVR_REQUIRE(!labels || (les && labels_strides), "svr_upload_region: bad labels dtype/strides");
+    if (!density && !labels) return SVR_OK;
+    if (shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return SVR_OK;
+    DeviceGuard guard(c->device);
+    rc = ensure_staging(c);
+    if (rc) return rc;
+    rc = uploads_after_render(c);
+    if (rc) return rc;
+    LodStorage& L = c->lod[lod];
+    const size_t plane_vox = (size_t)shape[0] * (size_t)shape[1];
+    // labels are placed after the density block, 16-byte aligned
+    const size_t per_z = plane_vox * (des + les) + 32;
+    SVR_REQUIRE(per_z <= c->slot_bytes, "svr_upload_region: one z-plane of the region exceeds the staging slot");
+    const int zs_max = (int)std::max<size_t>(1, (c->slot_bytes - 32) / (plane_vox * (des + les)));
+    for (int z0 = 0; z0 < shape[2]; z0 += zs_max) {
+        const int z1 = std::min(shape[2], z0 + zs_max);
+        StagingSlot& S = c->slot[c->next_slot];
+        c->next_slot = (c->next_slot + 1) % svr_ctx::kSlots;
+        if (S.used) SVR_HIP_TRY(hipEventSynchronize(S.done));
+        const size_t dbytes = plane_vox * (size_t)(z1 - z0) * des;
+        const size_t lofs = (dbytes + 15) & ~(size_t)15;
+        const size_t lbytes = plane_vox * (size_t)(z1 - z0) * les;
+        if (density) pack_rows(static_cast<const char*>(density), des, density_strides, shape, z0, z1, static_cast<char*>(S.host));
+        if (labels) pack_rows(static_cast<const char*>(labels), les, labels_strides, shape, z0, z1, static_cast<char*>(S.host) + lofs);
+        SVR_HIP_TRY(hipMemcpyAsync(S.dev, S.host, lofs + lbytes, hipMemcpyHostToDevice, c->upload_stream));
+        ScatterArgs a;
+        a.src_density = density ? S.dev : nullptr; a.density_dtype = density_dtype;
+        a.dstride[0] = (int64_t)des; a.dstride[1] = (int64_t)des * shape[0]; a.dstride[2] = (int64_t)des * shape[0] * shape[1];
+        a.src_labels = labels ? static_cast<char*>(S.dev) + lofs : nullptr; a.labels_dtype = labels_dtype;
+        a.lstride[0] = (int64_t)les; a.lstride[1] = (int64_t)les * shape[0]; a.lstride[2] = (int64_t)les * shape[0] * shape[1];
+        a.ring_density = L.density; a.ring_labels = L.labels;
+        for (int i = 0; i < 3; ++i) { a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i]; }
+        a.dst_off[2] = dst_off[2] + z0; a.shape[2] = z1 - z0;
+        SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
+        SVR_HIP_TRY(hipEventRecord(S.done, c->upload_stream));
+        S.used = true;
+    }
+    return SVR_OK;
+}
+
+int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], const int32_t shape[3],
+                             const void* density, int density_dtype, const int64_t density_strides[3],
+                             const void* labels, int labels_dtype, const int64_t labels_strides[3]) {
+    int rc = check_region(c, lod, dst_off, shape, "svr_upload_region_device");
+    if (rc) return rc;
+    SVR_REQUIRE(!density || (svr_dtype_size(density_dtype) && density_strides), "svr_upload_region_device: bad density dtype/strides");
+    SVR_REQUIRE(!labels || (svr_dtype_size(labels_dtype) && labels_strides), "svr_upload_region_device: bad labels dtype/strides");
+    if (!density && !labels) return SVR_OK;
+    DeviceGuard guard(c->device);
+    rc = uploads_after_render(c);
+    if (rc) return rc;
+    LodStorage& L = c->lod[lod];
+    ScatterArgs a;
+    a.src_density = density; a.density_dtype = density_dtype;
+    a.src_labels = labels; a.labels_dtype = labels_dtype;
+    for (int i = 0; i < 3; ++i) {
+        a.dstride[i] = density ? density_strides[i] : 0;
+        a.lstride[i] = labels ? labels_strides[i] : 0;
+        a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i];
+    }
+    a.ring_density = L.density; a.ring_labels = L.labels;
+    SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
+    return SVR_OK;
+}
+
+int svr_publish_uploads(svr_ctx* c) {
+    SVR_REQUIRE(c, "svr_publish_uploads: null ctx");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipEventRecord(c->uploads_published, c->upload_stream));
+    c->have_published = true;
+    return SVR_OK;
+}
+
+int svr_clear_lod(svr_ctx* c, int lod) {
+    SVR_REQUIRE(c, "svr_clear_lod: null ctx");
+    SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_clear_lod: lod out of range");
+    DeviceGuard guard(c->device);
+    int rc = uploads_after_render(c);
+    if (rc) return rc;
+    LodStorage& L = c->lod[lod];
+    SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * sizeof(float), c->upload_stream));
+    SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
+    return SVR_OK;
+}
+
+int svr_read_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t shape[3],
+                    float* density_out, uint32_t* labels_out) {
+    int rc = check_region(c, lod, off, shape, "svr_read_region");
+    if (rc) return rc;
+    const size_t n = (size_t)shape[0] * (size_t)shape[1] * (size_t)shape[2];
+    if (n == 0 || (!density_out && !labels_out)) return SVR_OK;
+    DeviceGuard guard(c->device);
+    LodStorage& L = c->lod[lod];
+    float* dtmp = nullptr; uint32_t* ltmp = nullptr;
+    SVR_HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    if (density_out) SVR_HIP_TRY(hipMalloc((void**)&dtmp, n * sizeof(float)));
+    if (labels_out && hipMalloc((void**)&ltmp, n * sizeof(uint32_t)) != hipSuccess) {
+        if (dtmp) (void)hipFree(dtmp);
+        svr_set_error("svr_read_region: out of device memory"); return SVR_ERR_NOMEM;
+    }
+    hipError_t e = svr_launch_gather(L.density, L.labels, L.ring, off, shape, dtmp, ltmp, c->upload_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->upload_stream);
+    if (e == hipSuccess && dtmp) e = hipMemcpy(density_out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ltmp) e = hipMemcpy(labels_out, ltmp, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (dtmp) (void)hipFree(dtmp);
+    if (ltmp) (void)hipFree(ltmp);
+    if (e != hipSuccess) { svr_set_error(std::string("svr_read_region: ") + hipGetErrorString(e)); return SVR_ERR_HIP; }
+    return SVR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the draw
+// ---------------------------------------------------------------------------
+static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, MarchParams& P) {
+    SVR_REQUIRE(c && cam && fr && out && out->rgba, "svr_render: null argument");
+    SVR_REQUIRE(c->material_set, "svr_render: svr_set_material has not been called");
+    SVR_REQUIRE(fr->frame_w > 0 && fr->frame_h > 0 && fr->out_w > 0 && fr->out_h > 0, "svr_render: empty frame");
+    SVR_REQUIRE(fr->x0 >= 0 && fr->y0 >= 0, "svr_render: negative tile origin");
+    memset(&P, 0, sizeof(P));
+    float tmp[16];
+    mat_mul4(cam->world_inv, cam->cam_inv, tmp);            // vs_main.wgsl:22 (left-assoc)
+    mat_mul4(tmp, cam->proj_inv, P.ndc_to_data);
+    mat_mul4(cam->proj, cam->cam, P.pc);                    // vs_main.wgsl:19
+    memcpy(P.world, cam->world, sizeof(P.world));
+    for (int a = 0; a < 3; ++a) {
+        SVR_REQUIRE(cam->volume_dimensions[a] >= 1.0f, "svr_render: volume_dimensions must be >= 1");
+        P.size[a] = cam->volume_dimensions[a];
+    }
+    const float mx = fmaxf(P.size[0], fmaxf(P.size[1], P.size[2]));
+    P.rel_step = fminf(fmaxf(sqrtf(mx) / 20.0f, 0.1f), 0.8f);   // fs_main.wgsl:20
+    P.frame = *fr;
+    if (P.frame.band_h <= 0) { P.frame.band_h = fr->out_h; P.frame.band_pitch = fr->out_h; }
+    const svr_material& m = c->material;
+    P.clim0 = m.clim[0]; P.clim1 = m.clim[1]; P.gamma = m.gamma; P.opacity = m.opacity;
+    P.lmip_threshold = m.lmip_threshold; P.lmip_fall_off = m.lmip_fall_off;
+    P.lmip_max_samples = m.lmip_max_samples; P.fog_density = m.fog_density;
+    for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
+    P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
+    P.num_lods = c->num_lods;
+    P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
+    P.tiles_x = (fr->out_w + 15) / 16; P.tiles_y = (fr->out_h + 15) / 16;
+    for (int l = 0; l < c->num_lods; ++l) {
+        const LodStorage& L = c->lod[l];
+        LodParams& Q = P.lod[l];
+        Q.density = L.density; Q.labels = L.labels;
+        for (int a = 0; a < 3; ++a) {
+            Q.off[a] = L.state.offset[a];
+            Q.shape[a] = (uint32_t)L.state.shape[a];
+            Q.ring[a] = (uint32_t)L.ring[a];
+            Q.wrap0[a] = (uint32_t)(L.state.offset[a] - floor_div(L.state.offset[a], L.ring[a]) * L.ring[a]);
+            Q.scale[a] = L.state.scale[a];
+        }
+    }
+    return SVR_OK;
+}
+
+int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, void* stream) {
+    MarchParams P;
+    int rc = fill_params(c, cam, fr, out, P);
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->render_stream;
+    if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
+    SVR_HIP_TRY(svr_launch_march(P, c->variant, s));
+    SVR_HIP_TRY(hipEventRecord(c->render_done, s));
+    c->render_pending = true;
+    return SVR_OK;
+}
+
+int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out,
+                    int iters, float* avg_ms) {
+    SVR_REQUIRE(avg_ms && iters >= 1, "svr_time_render: bad arguments");
+    MarchParams P;
+    int rc = fill_params(c, cam, fr, out, P);
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
+    hipStream_t s = c->render_stream;
+    if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
+    SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
+    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, c->variant, s));
+    SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
+    SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
+    float ms = 0.f;
+    SVR_HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+    *avg_ms = ms / (float)iters;
+    return SVR_OK;
+}
+
+int svr_untile_stripes(svr_ctx* c, const void* gathered, void* frame_out, int frame_w, int frame_h,
+                       int band_h, int nranks, int out_h, int elem_bytes, void* stream) {
+    SVR_REQUIRE(c && gathered && frame_out, "svr_untile_stripes: null argument");
+    SVR_REQUIRE(frame_w > 0 && frame_h > 0 && band_h > 0 && nranks > 0, "svr_untile_stripes: bad geometry");
+    const int nbands = (frame_h + band_h - 1) / band_h;
+    SVR_REQUIRE(out_h >= ((nbands + nranks - 1) / nranks) * band_h, "svr_untile_stripes: out_h too small for the frame");
+    DeviceGuard guard(c->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->render_stream;
+    SVR_HIP_TRY(svr_launch_untile(gathered, frame_out, frame_w, frame_h, band_h, nranks, out_h, elem_bytes, s));
+    return SVR_OK;
+}
+
+int svr_sync(svr_ctx* c) {
+    SVR_REQUIRE(c, "svr_sync: null ctx");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    SVR_HIP_TRY(hipStreamSynchronize(c->render_stream));
+    return SVR_OK;
+}
+
+int svr_sync_uploads(svr_ctx* c) {
+    SVR_REQUIRE(c, "svr_sync_uploads: null ctx");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    return SVR_OK;
+}
+
+int svr_lod_device_ptrs(svr_ctx* c, int lod, void** density, void** labels) {
+    SVR_REQUIRE(c, "svr_lod_device_ptrs: null ctx");
+    SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_lod_device_ptrs: lod out of range");
+    if (density) *density = c->lod[lod].density;
+    if (labels) *labels = c->lod[lod].labels;
+    return SVR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal declarations shared by the HIP translation units of libsvr_hip.so.
+// gfx950 (MI355X) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/svr.h"
+
+// ---------------------------------------------------------------------------
+// Kernel parameter block.  Passed BY VALUE as the single kernel argument: it
+// lives in the kernarg segment and is read with scalar loads, so every field is
+// wave-uniform SGPR data (the reference reads the same values from uniform
+// buffers each step: raycast.wgsl:16-20, sample_vol.wgsl:7,14-15).
+// ---------------------------------------------------------------------------
+struct LodParams {
+    const float*    density;   // ring texture r32float, [z][y][x]
+    const uint32_t* labels;    // ring texture r32uint
+    int32_t  off[3];           // current_logical_offset_in_pixels (x,y,z)
+    uint32_t shape[3];         // current_logical_shape_in_pixels
+    uint32_t wrap0[3];         // off - floor(off/ring)*ring  (ring slot of the ROI's first voxel)
+    uint32_t ring[3];          // ring extent
+    float    scale[3];         // scale_factor
+    uint32_t pad_;
+};
+
+struct MarchParams {
+    float ndc_to_data[16];     // world_inv * cam_inv * proj_inv   (vs_main.wgsl:22)
+    float pc[16];              // proj * cam                        (vs_main.wgsl:19)
+    float world[16];           // world_transform                   (fs_main.wgsl:62)
+    float size[3];             // volume_dimensions (x,y,z)
+    float rel_step;            // fs_main.wgsl:20
+    svr_frame frame;
+    // u_material
+    float clim0, clim1, gamma, opacity;
+    float lmip_threshold, lmip_fall_off;
+    int32_t lmip_max_samples;
+    float fog_density;
+    float fog_color[3];
+    uint32_t color_count;
+    const float* colors;       // device, color_count x vec4
+    int32_t colorspace_srgb;
+    int32_t num_lods;
+    // outputs (device)
+    float*    rgba;
+    float*    depth;
+    uint32_t* label;
+    uint8_t*  flags;
+    uint32_t* steps;
+    // block -> tile mapping
+    int32_t tiles_x, tiles_y;
+    LodParams lod[SVR_MAX_LODS];
+};
+
+struct LodStorage {
+    int32_t  ring[3];          // x,y,z
+    size_t   voxels;
+    float*    density;
+    uint32_t* labels;
+    svr_lod_state state;
+};
+
+struct StagingSlot {
+    void* host;                // pinned
+    void* dev;
+    hipEvent_t done;           // scatter kernel that consumed this slot has finished
+    bool used;
+};
+
+struct svr_ctx {
+    int device;
+    int num_lods;
+    LodStorage lod[SVR_MAX_LODS];
+    hipStream_t render_stream;
+    hipStream_t upload_stream;
+    hipEvent_t  uploads_published;   // recorded on upload_stream by svr_publish_uploads
+    bool        have_published;
+    // material (device copy of the colour table)
+    svr_material material;
+    std::vector<float> colors_host;
+    float* colors_dev;
+    uint32_t colors_cap;
+    bool material_set;
+    int variant;
+    // pinned staging ring for host uploads
+    static constexpr int kSlots = 3;
+    size_t slot_bytes;
+    StagingSlot slot[kSlots];
+    int next_slot;
+    hipEvent_t ev_a, ev_b;           // timing
+    hipEvent_t render_done;          // recorded after the last enqueued render
+    bool       render_pending;
+};
+
+// error plumbing -------------------------------------------------------------
+void svr_set_error(const std::string& msg);
+#define SVR_HIP_TRY(expr)                                                            \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            svr_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+            return SVR_ERR_HIP;                                                      \
+        }                                                                            \
+    } while (0)
+
+// kernels (march_kernel.hip / ring_kernels.hip) ------------------------------
+hipError_t svr_launch_march(const MarchParams& p, int variant, hipStream_t stream);
+
+struct ScatterArgs {
+    const void* src_density; int density_dtype; int64_t dstride[3];   // bytes per x,y,z step
+    const void* src_labels;  int labels_dtype;  int64_t lstride[3];
+    float* ring_density; uint32_t* ring_labels;
+    int32_t ring[3];
+    int32_t dst_off[3];
+    int32_t shape[3];
+};
+hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
+hipError_t svr_launch_gather(const float* ring_density, const uint32_t* ring_labels, const int32_t ring[3],
+                             const int32_t off[3], const int32_t shape[3],
+                             float* out_density, uint32_t* out_labels, hipStream_t stream);
+hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,
+                             int band_h, int nranks, int out_h, int elem_bytes, hipStream_t stream);
+
+size_t svr_dtype_size(int dtype);

@@ -1,0 +1,173 @@
+"""Scene descriptions shared by tests, smoke() and bench.py.
+
+A :class:`SceneSpec` is *inputs only* (arrays, shapes, material arguments, camera
+pose, the sequence of ``center_on_position`` calls).  The product builds a
+``SubVolume`` from it (:func:`build`); the oracle (``oracle/lmip.py``) builds its
+own restatement from the same spec.  This module never imports the oracle.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._material import SubVolumeMaterial
+from ._transform import AffineTransform, PerspectiveCamera
+from ._wobject import FrameRegion, RenderResult, SubVolume
+
+
+@dataclass
+class SceneSpec:
+    pairs: list                                   # [(density, labels)] per LOD, numpy-like
+    chunk_shapes: list
+    ring_shapes: list                             # buffer_shape_in_chunks
+    material: dict
+    width: int
+    height: int
+    cam_position: tuple = (0.0, 0.0, 0.0)
+    cam_target: tuple = (0.0, 0.0, -1.0)
+    fov: float = 45.0
+    depth_range: tuple = (0.1, 1000.0)
+    world_position: tuple = (0.0, 0.0, 0.0)
+    world_scale: tuple = (1.0, 1.0, 1.0)
+    centers: list = field(default_factory=list)   # [(position_xyz, sizes | None)]
+    region: FrameRegion | None = None
+    colorspace: str = "srgb"
+
+    def camera(self) -> PerspectiveCamera:
+        cam = PerspectiveCamera(self.fov, self.width / self.height, depth_range=self.depth_range)
+        cam.world.position = self.cam_position
+        cam.look_at(self.cam_target)
+        return cam
+
+    def world(self) -> AffineTransform:
+        t = AffineTransform()
+        t.position = self.world_position
+        t.scale = self.world_scale
+        return t
+
+    def matrices(self) -> dict:
+        """The six mat4 of ``svr_camera`` as row-major float32 numpy arrays."""
+        cam, world = self.camera(), self.world()
+        m = {
+            "world": world.matrix, "world_inv": world.inverse_matrix,
+            "cam": cam.view_matrix, "cam_inv": cam.camera_matrix,
+            "proj": cam.projection_matrix, "proj_inv": cam.projection_matrix_inverse,
+        }
+        return {k: np.asarray(v, np.float32) for k, v in m.items()}
+
+
+@dataclass
+class BuiltScene:
+    spec: SceneSpec
+    volume: SubVolume
+    camera: PerspectiveCamera
+    width: int
+    height: int
+
+
+def build(spec: SceneSpec, device: int | None = None) -> BuiltScene:
+    """Product side: a ``SubVolume`` with the spec's loads applied (needs the GPU)."""
+    vol = SubVolume(
+        SubVolumeMaterial(**spec.material),
+        data_segmentation_pairs=list(spec.pairs),
+        buffer_shape_in_chunks=list(spec.ring_shapes),
+        chunk_shape_in_pixels=list(spec.chunk_shapes),
+        device=device,
+    )
+    vol.world.position = spec.world_position
+    vol.world.scale = spec.world_scale
+    for b in vol.wrapping_buffers:
+        b.texture.colorspace = spec.colorspace
+    for position, sizes in spec.centers:
+        vol.center_on_position(position, sizes)
+    return BuiltScene(spec, vol, spec.camera(), spec.width, spec.height)
+
+
+# ---------------------------------------------------------------------------
+# canned scenes
+# ---------------------------------------------------------------------------
+def multiscale_demo_spec(width: int = 480, height: int = 480, tiles: int = 16) -> SceneSpec:
+    """BASELINE config 1: the literal arrays, material, ring shapes and camera of the
+    reference's ``scripts/multi_scale.py:31-85`` (``tiles=16`` gives its
+    (256,256,768)/(128,128,768)/(64,64,768) volumes)."""
+    chunk_0 = np.zeros((16, 16, 48))
+    chunk_0[:4, :4, :4] = 1
+    chunk_1 = np.zeros((8, 8, 48))
+    chunk_1[:2, :2, :4] = 1
+    chunk_2 = np.zeros((4, 4, 48))
+    chunk_2[:1, :1, :4] = 1
+    datas = [np.tile(c, (tiles, tiles, tiles)) for c in (chunk_0, chunk_1, chunk_2)]
+    segs = [k * np.ones(d.shape, dtype=np.uint8) for k, d in enumerate(datas)]
+    cam_pos = (-19.81, 7.5, 7.5)
+    return SceneSpec(
+        pairs=list(zip(datas, segs)),
+        chunk_shapes=[(16, 16, 48), (8, 8, 48), (4, 4, 48)],
+        ring_shapes=[(2, 2, 2), (4, 4, 4), (8, 8, 8)],
+        material=dict(lmip_threshold=0.5, fog_density=0.01,
+                      colors=[(0.0, 1.0, 1.0), (0.33, 1.0, 1.0), (0.66, 1.0, 1.0)]),
+        width=width, height=height,
+        cam_position=cam_pos, cam_target=(-1.0, 0.0, 0.0), fov=45.0, depth_range=(0.05, 5000.0),
+        centers=[(cam_pos, None)],
+    )
+
+
+def make_multiscale_demo_scene(width: int = 480, height: int = 480, tiles: int = 4) -> BuiltScene:
+    return build(multiscale_demo_spec(width, height, tiles))
+
+
+def synthetic_spec(n: int = 64, width: int = 96, height: int = 64, *, inside: bool = False,
+                   threshold: float = 0.5, full: bool = False, n_labels: int = 4096,
+                   chunk_shapes=None, ring_shapes=None, sizes=None, fog_density: float = 0.01,
+                   ncolors: int = 4, pairs=None) -> SceneSpec:
+    """A small 3-LOD synthetic scene with the structure of BASELINE config 2
+    (SURVEY.md §8d): LOD0 window around the volume centre, coarser LODs covering more."""
+    from . import synth
+
+    if pairs is None:
+        pairs = [synth.volume(n, k, n_labels) for k in range(3)]
+    chunk_shapes = chunk_shapes or [(8, 8, 16), (4, 4, 16), (2, 2, 16)]
+    ring_shapes = ring_shapes or [(5, 5, 3), (8, 8, 2), (8, 8, 1)]
+    c = (n - 1) / 2.0
+    centre = np.array([c, c, c])
+    if inside:
+        eye = centre + np.array([0.1 * n, 0.05 * n, -0.2 * n])
+        target = eye + np.array([0.6, 0.3, 0.74])
+    else:
+        d = np.array([-0.80, 0.36, 0.48])
+        eye = centre + 1.6 * n * d / np.linalg.norm(d)
+        target = centre
+    colors = [(k / ncolors, 1.0, 1.0) for k in range(ncolors)]
+    return SceneSpec(
+        pairs=pairs, chunk_shapes=chunk_shapes, ring_shapes=ring_shapes,
+        material=dict(lmip_threshold=float("inf") if full else threshold * 255.0, lmip_fall_off=0.5,
+                      lmip_max_samples=10, fog_density=fog_density, fog_color=(0.5, 0.5, 0.5),
+                      colors=colors, clim=(0.0, 255.0)),
+        width=width, height=height,
+        cam_position=tuple(eye), cam_target=tuple(target), fov=45.0,
+        depth_range=(n / 500.0, n * 20.0),
+        centers=[(tuple(centre), sizes)],
+    )
+
+
+# ---------------------------------------------------------------------------
+def compare(res: RenderResult, ref) -> dict:
+    """Compare a device render with an oracle result (numpy arrays with the same
+    attribute names).  Integer planes must match exactly; float planes are reported
+    as max abs / max relative-or-abs error."""
+    rgba = res.rgba.cpu().numpy()
+    out = {
+        "flags_equal": bool(np.array_equal(res.flags.cpu().numpy(), ref.flags)),
+        "labels_equal": bool(np.array_equal(res.label.cpu().numpy().view(np.uint32), ref.label)),
+        "rgba_max_abs": float(np.max(np.abs(rgba - ref.rgba))) if rgba.size else 0.0,
+        "rgba_max_rel": float(np.max(np.abs(rgba - ref.rgba) / np.maximum(1.0, np.abs(ref.rgba)))) if rgba.size else 0.0,
+        "depth_max_abs": float(np.max(np.abs(res.depth.cpu().numpy() - ref.depth))) if rgba.size else 0.0,
+        "n_hit": int(np.count_nonzero(ref.flags == 2)),
+        "n_miss": int(np.count_nonzero(ref.flags == 1)),
+        "n_discard": int(np.count_nonzero(ref.flags == 0)),
+    }
+    if res.steps is not None and getattr(ref, "steps", None) is not None:
+        out["steps_equal"] = bool(np.array_equal(res.steps.cpu().numpy().view(np.uint32), ref.steps))
+        out["total_steps"] = int(ref.steps.astype(np.int64).sum())
+    return out

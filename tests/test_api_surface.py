@@ -1,0 +1,157 @@
+"""The drop-in surface (no GPU): constructor signatures, defaults, validation errors of the
+reference's classes (src/sub_volume/_material.py, _wobject.py, _wrapping_buffer.py), and the C ABI:
+libsvr_hip.so loads and exports every symbol include/svr.h declares."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sub_volume_renderer_amd as svr
+from sub_volume_renderer_amd import SubVolume, SubVolumeMaterial, WrappingBuffer, _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI -------------------------------------------------------------------
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "svr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svr_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_bound_and_exported():
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    assert set(syms) == set(_native.SIGNATURES)            # the binding covers the header exactly
+    lib = ctypes.CDLL(_native.LIB_PATH)                    # loads without a GPU
+    for s in syms:
+        assert hasattr(lib, s), f"{s} not exported by libsvr_hip.so"
+
+
+def test_abi_version_and_struct_sizes():
+    lib = _native.lib()
+    assert lib.svr_abi_version() == 1
+    assert ctypes.sizeof(_native.LodState) == 36            # 3xi4 + 3xi4 + 3xf4 (_wrapping_buffer.py:15-19)
+    assert ctypes.sizeof(_native.Camera) == 6 * 64 + 12
+    assert ctypes.sizeof(_native.Frame) == 32
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    data = np.zeros((8, 8, 8), np.uint8)
+    buf = WrappingBuffer(data, data, (2, 2, 2), (2, 2, 2))
+    with pytest.raises(Exception):                          # no silent CPU fallback
+        buf.load_logical_roi(svr.Roi((0, 0, 0), (2, 2, 2)))
+
+
+def test_exports():
+    for name in ("SubVolume", "SubVolumeMaterial", "WrappingBuffer"):      # sub_volume/__init__.py:17-21
+        assert name in svr.__all__
+
+
+# ---- SubVolumeMaterial (_material.py:26-159) ----------------------------------
+def test_material_signature_and_defaults():
+    sig = inspect.signature(SubVolumeMaterial.__init__)
+    names = list(sig.parameters)[1:]
+    assert names == ["lmip_threshold", "lmip_fall_off", "lmip_max_samples", "fog_density", "fog_color",
+                     "colors", "clim", "gamma", "opacity"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["lmip_fall_off"] == 0.5 and d["lmip_max_samples"] == 10 and d["fog_density"] == 0.5
+    assert d["fog_color"] == (0.5, 0.5, 0.5) and d["colors"] is None and d["clim"] == (0, 1)
+    assert d["gamma"] == 1.0 and d["opacity"] == 1.0
+    m = SubVolumeMaterial(0.5)
+    assert float(m.lmip_threshold) == 0.5 and int(m.lmip_max_samples) == 10
+    assert m.fog_color == (0.5, 0.5, 0.5)
+    assert m.colors == [(0.0, 1.0, 1.0, 1.0), (0.25, 1.0, 1.0, 1.0), (0.5, 1.0, 1.0, 1.0), (0.75, 1.0, 1.0, 1.0)]
+    assert int(m._color_count) == 4 and m.clim == (0.0, 1.0) and m.depth_test is True
+
+
+def test_material_validation():
+    m = SubVolumeMaterial(0.5)
+    with pytest.raises(ValueError):
+        m.fog_color = (0.1, 0.2)
+    with pytest.raises(ValueError):
+        m.fog_color = (0.1, "a", 0.2)
+    with pytest.raises(ValueError):
+        m.fog_color = (0.1, 1.5, 0.2)
+    with pytest.raises(TypeError):
+        m.colors = "red"
+    with pytest.raises(TypeError):
+        m.colors = [(0.1, 0.2)]
+    v = m._version
+    m.lmip_max_samples = 7.9
+    assert int(m.lmip_max_samples) == 7 and m._version > v   # i32 field (_material.py:10-11)
+    m.colors = [(0.1, 0.2, 0.3)]
+    assert int(m._color_count) == 1 and m.colors[0][3] == 1.0
+
+
+# ---- SubVolume (_wobject.py:20-208) ---------------------------------------------
+def pairs(n=3, base=32):
+    out = []
+    for k in range(n):
+        s = base >> k
+        out.append((np.zeros((s, s, 2 * s), np.uint8), np.zeros((s, s, 2 * s), np.uint32)))
+    return out
+
+
+def test_subvolume_signature():
+    names = list(inspect.signature(SubVolume.__init__).parameters)[1:5]
+    assert names == ["material", "data_segmentation_pairs", "buffer_shape_in_chunks", "chunk_shape_in_pixels"]
+    names = list(inspect.signature(SubVolume.center_on_position).parameters)[1:]
+    assert names == ["position", "sizes"]
+    names = list(inspect.signature(WrappingBuffer.__init__).parameters)[1:6]
+    assert names == ["backing_data", "segmentations", "shape_in_chunks", "chunk_shape_in_pixels", "scale_factor"]
+
+
+def test_subvolume_construction_and_validation():
+    m = SubVolumeMaterial(0.5)
+    v = SubVolume(m, pairs(), [(2, 2, 2), (3, 3, 3), (4, 4, 4)], [(8, 8, 8), (4, 4, 4), (2, 2, 2)])
+    assert len(v.wrapping_buffers) == 3 and len(v.textures) == 3 and len(v.segmentations_textures) == 3
+    assert v.volume_dimensions == (32.0, 32.0, 64.0)                       # numpy order (_wobject.py:103-107)
+    assert tuple(v._volume_dimensions) == (64.0, 32.0, 32.0)               # uniform is reversed (:121-123)
+    assert v.wrapping_buffers[1].scale_factor == (0.5, 0.5, 0.5)
+    assert tuple(v.wrapping_buffers[1].shape_in_pixels) == (12, 12, 12)
+    assert v.wrapping_buffers[0]._current_logical_roi_in_pixels is None
+    u = v.wrapping_buffers[2].uniform_buffer.data
+    assert tuple(u["current_logical_shape_in_pixels"]) == (0, 0, 0)        # ROI None <-> zeros (:90-96)
+    # a tuple broadcasts to every scale (:34-36, :54-56)
+    v2 = SubVolume(m, pairs(), (2, 2, 2), (4, 4, 4))
+    assert [tuple(b.shape_in_pixels) for b in v2.wrapping_buffers] == [(8, 8, 8)] * 3
+    with pytest.raises(ValueError):
+        SubVolume(m, pairs(), [(2, 2, 2)], [(8, 8, 8)] * 3)                # :40-43
+    with pytest.raises(ValueError):
+        SubVolume(m, pairs(), [(2, 2, 2)] * 3, [(8, 8, 8)] * 2)            # :60-63
+    with pytest.raises(ValueError):
+        SubVolume(m, pairs(), [(2, 2, 2)] * 3, None)                       # no .chunks (:46-53)
+    with pytest.raises(ValueError):
+        SubVolume(m, pairs(), [(2, 2, 2)] * 3, [(8, 8)] * 3)               # rank mismatch (:66-70)
+
+    class Chunked(np.ndarray):
+        chunks = (4, 4, 4)
+
+    p = [(d.view(Chunked), s) for d, s in pairs()]
+    v3 = SubVolume(m, p, (2, 2, 2))
+    assert tuple(v3.wrapping_buffers[2].chunk_shape_in_pixels) == (4, 4, 4)
+    with pytest.raises(ValueError):
+        v.center_on_position((0, 0, 0), sizes=[(1, 1, 1)])                 # :178-181
+
+
+def test_world_transform_and_camera_matrices():
+    cam = svr.PerspectiveCamera(45, 16 / 9, depth_range=(1.0, 100.0))
+    cam.world.position = (3.0, 4.0, 5.0)
+    cam.look_at((0.0, 0.0, 0.0))
+    v = cam.view_matrix @ np.array([0.0, 0.0, 0.0, 1.0])
+    assert abs(v[0]) < 1e-9 and abs(v[1]) < 1e-9 and v[2] < 0             # target on the -z axis
+    assert np.allclose(cam.view_matrix @ cam.camera_matrix, np.eye(4))
+    p = cam.projection_matrix
+    near = p @ np.array([0, 0, -1.0, 1]); far = p @ np.array([0, 0, -100.0, 1])
+    assert abs(near[2] / near[3]) < 1e-9 and abs(far[2] / far[3] - 1) < 1e-9   # depth range [0, 1]
+    t = svr.AffineTransform()
+    t.position = (1, 2, 3); t.scale_z = 6
+    assert np.allclose(t.inverse_matrix @ t.matrix, np.eye(4)) and t.matrix[2, 2] == 6

@@ -1,0 +1,181 @@
+"""GPU: the HIP LMIP march through the C ABI against the CPU oracle on identical inputs.
+Bar (BASELINE.json north_star): flags / labels / step counts bit-exact; RGBA and depth within 1e-4."""
+import numpy as np
+import pytest
+
+from oracle import lmip
+from sub_volume_renderer_amd import FrameRegion, testing
+
+pytestmark = pytest.mark.gpu
+
+RGBA_TOL = 1e-4      # absolute on values <= 1, relative above (raw-intensity scenes exceed 1)
+DEPTH_TOL = 1e-4
+
+
+def check(scene, region=None, ref=None, want_hits=True):
+    import torch
+
+    res = scene.volume.render(scene.camera, scene.width, scene.height, region=region, count_steps=True)
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = lmip.render_spec(scene.spec, region=region)
+    rep = testing.compare(res, ref)
+    assert rep["flags_equal"], rep
+    assert rep["labels_equal"], rep
+    assert rep["steps_equal"], rep
+    assert rep["rgba_max_rel"] <= RGBA_TOL, rep
+    assert rep["depth_max_abs"] <= DEPTH_TOL, rep
+    if want_hits:
+        assert rep["n_hit"] > 0, rep
+    return res, ref, rep
+
+
+def test_config1_multi_scale_demo():
+    """BASELINE config 1: scripts/multi_scale.py arrays/material/camera (reduced tiling), 3 LODs visible."""
+    scene = testing.build(testing.multiscale_demo_spec(240, 240, tiles=6))
+    _, ref, rep = check(scene)
+    assert set(np.unique(ref.label[ref.flags == 2])) == {0, 1, 2}      # every LOD contributes hits
+
+
+@pytest.mark.parametrize("inside", [False, True], ids=["K1_outside", "K2_inside"])
+@pytest.mark.parametrize("full", [False, True], ids=["lmip", "full"])
+def test_synthetic_three_lods(inside, full):
+    scene = testing.build(testing.synthetic_spec(64, 160, 96, inside=inside, full=full))
+    _, ref, rep = check(scene, want_hits=not full)
+    if full:
+        assert rep["n_hit"] == 0 and rep["n_miss"] > 0                 # threshold = +inf: every ray runs all nsteps
+
+
+def test_synthetic_128_srgb_off_and_many_colors():
+    spec = testing.synthetic_spec(128, 200, 120, threshold=0.3, fog_density=0.05, ncolors=256, n_labels=100003)
+    spec.colorspace = "linear"
+    spec.material.update(gamma=0.7, opacity=0.8, lmip_max_samples=3, lmip_fall_off=0.9)
+    scene = testing.build(spec)
+    check(scene)
+
+
+def test_single_lod_and_empty_rois():
+    from sub_volume_renderer_amd import synth
+
+    pairs = [synth.volume(32, 0)]
+    spec = testing.synthetic_spec(32, 96, 64, pairs=pairs, chunk_shapes=[(8, 8, 8)], ring_shapes=[(4, 4, 4)],
+                                  threshold=0.2)
+    scene = testing.build(spec)
+    check(scene)
+    # nothing loaded at all: ROI None -> offset = shape = 0 -> every sample is 0 -> all MISS, black, alpha 1
+    spec2 = testing.synthetic_spec(32, 64, 48, pairs=pairs, chunk_shapes=[(8, 8, 8)], ring_shapes=[(4, 4, 4)])
+    spec2.centers = []
+    scene2 = testing.build(spec2)
+    res, ref, rep = check(scene2, want_hits=False)
+    assert rep["n_hit"] == 0
+    rgba = res.rgba.cpu().numpy()
+    miss = ref.flags == 1
+    assert np.all(rgba[miss] == np.array([0, 0, 0, 1], np.float32))
+
+
+def test_world_transform_anisotropic_scale():
+    spec = testing.synthetic_spec(64, 128, 96)
+    spec.world_scale = (1.0, 1.0, 3.0)          # scripts/mouse.py:90-91 style (world.scale_z)
+    spec.world_position = (5.0, -3.0, 2.0)
+    c = 31.5
+    spec.cam_target = (c + 5.0, c - 3.0, 3 * c + 2.0)
+    spec.cam_position = (c - 90.0, c + 40.0, 3 * c + 60.0)
+    spec.centers = [((c + 5.0, c - 3.0, 3 * c + 2.0), None)]
+    check(testing.build(spec))
+
+
+def test_fly_through_sequence_of_centers():
+    """center_on_position per frame along a path: diff-loads + ring wrap-around, render after each."""
+    spec = testing.synthetic_spec(64, 96, 64, inside=True)
+    scene = testing.build(spec)
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    for k in range(1, 6):
+        p = eye + d * 5.0 * k
+        spec.cam_position = tuple(p)
+        spec.cam_target = tuple(p + d)
+        spec.centers.append((tuple(p), None))
+        scene.volume.center_on_position(tuple(p))
+        scene.camera = spec.camera()
+        check(scene, want_hits=False)
+
+
+def test_tiles_and_stripes_equal_full_frame():
+    scene = testing.build(testing.synthetic_spec(64, 200, 130))
+    _, full, _ = check(scene)
+    W, H = 200, 130
+    # 2 x 4 tile grid (BASELINE config 3 geometry), odd sizes on purpose
+    for ty in range(4):
+        for tx in range(2):
+            x0, y0 = tx * 100, ty * 33
+            w, h = 100, min(33, H - y0) if ty < 3 else H - y0
+            reg = FrameRegion.tile(x0, y0, w, h)
+            res, ref, _ = check(scene, region=reg, want_hits=False)
+            np.testing.assert_array_equal(ref.label, full.label[y0:y0 + h, x0:x0 + w])
+            np.testing.assert_array_equal(res.rgba.cpu().numpy(), _render_full(scene)[y0:y0 + h, x0:x0 + w])
+    # interleaved stripes for 3 ranks, 8-row bands, padded
+    whole = _render_full(scene)
+    for rank in range(3):
+        reg = FrameRegion.stripes(W, H, rank, 3, band_h=8)
+        res, ref, _ = check(scene, region=reg, want_hits=False)
+        got = res.rgba.cpu().numpy()
+        for r in range(reg.out_h):
+            y = reg.y0 + (r // 8) * reg.band_pitch + r % 8
+            if y < H:
+                np.testing.assert_array_equal(got[r], whole[y])
+            else:
+                assert np.all(got[r] == 0)           # padding rows are "discarded"
+
+
+_full_cache = {}
+
+
+def _render_full(scene):
+    import torch
+
+    key = id(scene)
+    if key not in _full_cache:
+        r = scene.volume.render(scene.camera, scene.width, scene.height)
+        torch.cuda.synchronize()
+        _full_cache[key] = r.rgba.cpu().numpy().copy()
+    return _full_cache[key]
+
+
+def test_untile_stripes_roundtrip():
+    import ctypes as C
+
+    import torch
+
+    from sub_volume_renderer_amd import _native as N
+
+    scene = testing.build(testing.synthetic_spec(64, 120, 70))
+    whole = _render_full(scene)
+    W, H, nr, bh = 120, 70, 4, 8
+    parts = []
+    for rank in range(nr):
+        reg = FrameRegion.stripes(W, H, rank, nr, band_h=bh)
+        r = scene.volume.render(scene.camera, W, H, region=reg)
+        torch.cuda.synchronize()
+        parts.append(r.rgba.clone())
+    gathered = torch.stack(parts)                     # [nranks, out_h, W, 4] == what the RCCL gather delivers
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    N.check(N.lib().svr_untile_stripes(scene.volume._rings.handle, C.c_void_p(gathered.data_ptr()),
+                                       C.c_void_p(out.data_ptr()), W, H, bh, nr, parts[0].shape[0], 16,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "untile")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), whole)
+
+
+def test_material_update_takes_effect():
+    scene = testing.build(testing.synthetic_spec(64, 96, 64))
+    check(scene)
+    scene.spec.material.update(lmip_threshold=0.25 * 255, fog_color=(0.1, 0.2, 0.3), fog_density=0.4)
+    m = scene.volume.material
+    m.lmip_threshold = 0.25 * 255
+    m.fog_color = (0.1, 0.2, 0.3)
+    m.fog_density = 0.4
+    check(scene)
+    scene.spec.material["colors"] = [(0.9, 0.5, 1.0), (0.1, 0.0, 1.0)]       # s == 0 branch of hsv_to_rgb
+    m.colors = scene.spec.material["colors"]
+    check(scene)
