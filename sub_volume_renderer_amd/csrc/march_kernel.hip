@@ -249,15 +249,237 @@ __global__ __launch_bounds__(256) void march_simple(const MarchParams P) {
     if (COUNT && P.steps) P.steps[o] = h.steps;
 }
 
+// ---------------------------------------------------------------------------
+// Variant 0 (default): batched march.
+//
+// Exactness argument.  For one ray and one axis, the voxel index the reference
+// computes at iteration i,
+//     ic(i) = i32( ((start + f32(i)*step) * size) * scale )        (raycast.wgsl:30-31,
+//                                                                   sample_vol.wgsl:6-8,17)
+// is a composition of monotone functions of i (IEEE rounding is monotone), so it is
+// monotone in i.  Hence "voxel i lies in LOD l's ROI" holds on ONE contiguous
+// iteration interval [A_l, B_l), whose ends are found exactly by evaluating that
+// same f32 chain (first_true below).  The cascade of sample_vol.wgsl:51-63 then is
+// "smallest l with A_l <= i < B_l".  With the intervals known, a wave whose lanes
+// are all inside the same LOD for a whole batch of U steps needs no bounds tests,
+// computes U texel offsets, issues U independent buffer loads (hardware range
+// check returns 0 for "no LOD"), and only then runs the sequential LMIP state
+// machine — skipped entirely while no lane has reached the threshold.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int axis_voxel(int i, float start, float step, float size, float scale) {
+    float off = (float)i * step;          // raycast.wgsl:30  (iter is an exact integer-valued f32)
+    float coord = start + off;            // :31
+    float d = coord * size;               // sample_vol.wgsl:6
+    float sd = d * scale;                 // :7-8
+    return (int)sd;                       // :17 vec3<i32>()
+}
+
+// smallest i in [0, n] with pred(i), for a monotone (false.. true..) predicate
+template <class Pred>
+__device__ __forceinline__ int first_true(float guess, int n, Pred pred) {
+    int i = (int)fminf(fmaxf(guess, 0.0f), (float)n);
+    while (i > 0 && pred(i - 1)) --i;
+    while (i < n && !pred(i)) ++i;
+    return i;
+}
+
+// iterations for which lo <= ic(i) < hi on one axis: [enter, exit)
+__device__ __forceinline__ void axis_interval(int n, float start, float step, float size, float scale,
+                                              int lo, int hi, int& enter, int& exit) {
+    auto g = [&](int i) { return axis_voxel(i, start, step, size, scale); };
+    if (!(step > 0.0f) && !(step < 0.0f)) {           // zero (or NaN) step: constant along the ray
+        const int v = g(0);
+        const bool in = lo <= v && v < hi;
+        enter = 0; exit = in ? n : 0;
+        return;
+    }
+    const float k = size * scale;
+    const float glo = ceilf(((float)lo / k - start) / step);
+    const float ghi = ceilf(((float)hi / k - start) / step);
+    if (step > 0.0f) {
+        enter = first_true(glo, n, [&](int i) { return g(i) >= lo; });
+        exit  = first_true(ghi, n, [&](int i) { return g(i) >= hi; });
+    } else {
+        enter = first_true(ghi, n, [&](int i) { return g(i) < hi; });
+        exit  = first_true(glo, n, [&](int i) { return g(i) < lo; });
+    }
+}
+
+// byte offset of the texel under data coord d inside MarchParams::density_all, for a
+// voxel KNOWN to lie in LOD L's ROI (no bounds test)
+__device__ __forceinline__ uint32_t lod_offset_inside(const LodParams& L, float dx, float dy, float dz) {
+    float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
+    uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
+    uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
+    uint32_t wz = (uint32_t)((int)sz + L.addw[2]);
+    wx = min(wx, wx - L.ring[0]);
+    wy = min(wy, wy - L.ring[1]);
+    wz = min(wz, wz - L.ring[2]);
+    return (wz * L.ring[1] + wy) * L.rx4 + L.base_bytes + (wx << 2);
+}
+
+template <int NL, int U, bool COUNT>
+__global__ __launch_bounds__(256) void march_batched(const MarchParams P) {
+    const int nblocks = P.tiles_x * P.tiles_y;
+    const int t = xcd_remap((int)blockIdx.x, nblocks);
+    const int tile_x = t % P.tiles_x, tile_y = t / P.tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int r = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (c >= P.frame.out_w || r >= P.frame.out_h) return;
+    const size_t o = (size_t)r * (size_t)P.frame.out_w + (size_t)c;
+    const int x = P.frame.x0 + c;
+    const int y = P.frame.y0 + (r / P.frame.band_h) * P.frame.band_pitch + (r % P.frame.band_h);
+
+    Ray R;
+    R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
+    const bool frag = (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
+    const int nsteps = frag ? R.nsteps : 0;
+
+    // exact per-LOD iteration intervals
+    int A[NL], B[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        A[l] = 0; B[l] = 0;
+        if (frag) {
+            const LodParams& L = P.lod[l];
+            int e0, x0, e1, x1, e2, x2;
+            axis_interval(nsteps, R.start.x, R.step.x, P.size[0], L.scale[0], L.off[0], L.off[0] + (int)L.shape[0], e0, x0);
+            axis_interval(nsteps, R.start.y, R.step.y, P.size[1], L.scale[1], L.off[1], L.off[1] + (int)L.shape[1], e1, x1);
+            axis_interval(nsteps, R.start.z, R.step.z, P.size[2], L.scale[2], L.off[2], L.off[2] + (int)L.shape[2], e2, x2);
+            const int a = max(e0, max(e1, e2)), b = min(x0, min(x1, x2));
+            if (a < b) { A[l] = a; B[l] = b; }
+        }
+    }
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
+
+    bool found = false, finished = false;
+    float local_max = 0.f, samp = 0.f;
+    int hit_i = 0, since = 0;
+    uint32_t steps = 0;
+
+    for (int i = 0;; i += U) {
+        const bool active = !finished && i < nsteps;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        float s[U];
+        bool valid[U];
+        if (active) {
+            const int iend = min(i + U, nsteps);
+            // which LOD serves this whole batch for this lane?  NL = "none", -1 = mixed
+            int code = NL;
+            bool settled = false;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const bool inb = i >= A[l] && iend <= B[l];
+                const bool outb = iend <= A[l] || i >= B[l];
+                if (!settled) {
+                    if (inb) { code = l; settled = true; }
+                    else if (!outb) { code = -1; settled = true; }
+                }
+            }
+            const int first = __builtin_amdgcn_readfirstlane(code);
+            const bool uniform = first >= 0 && __builtin_amdgcn_ballot_w64(code != first) == 0;
+            uint32_t off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { off[u] = 0xFFFFFFFFu; valid[u] = (i + u) < nsteps; }
+            const float basef = (float)i;
+            if (uniform) {
+                if (first < NL) {
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        if (first == l) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const float iter = basef + (float)u;
+                                const float cx = R.start.x + iter * R.step.x;
+                                const float cy = R.start.y + iter * R.step.y;
+                                const float cz = R.start.z + iter * R.step.z;
+                                off[u] = lod_offset_inside(P.lod[l], cx * P.size[0], cy * P.size[1], cz * P.size[2]);
+                            }
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float iter = basef + (float)u;
+                    const float dx = (R.start.x + iter * R.step.x) * P.size[0];
+                    const float dy = (R.start.y + iter * R.step.y) * P.size[1];
+                    const float dz = (R.start.z + iter * R.step.z) * P.size[2];
+                    bool done = false;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        const bool sel = !done && (i + u) >= A[l] && (i + u) < B[l];
+                        if (__builtin_amdgcn_ballot_w64(sel) != 0) {
+                            const uint32_t ofs = lod_offset_inside(P.lod[l], dx, dy, dz);
+                            off[u] = sel ? ofs : off[u];
+                        }
+                        done = done || sel;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[u], 0, 0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s[u] = 0.f; valid[u] = false; }
+        }
+
+        // LMIP state machine (raycast.wgsl:35-61); skipped while nothing can change
+        float m = -1.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m = fmaxf(m, valid[u] ? fabsf(s[u]) : -1.0f);
+        const bool need = active && (found || m >= P.lmip_threshold);
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool act = active && valid[u] && !finished;
+                const float inten = fabsf(s[u]);
+                if (COUNT) steps += act ? 1u : 0u;
+                const bool was_found = found;
+                const bool first_hit = act && !was_found && inten >= P.lmip_threshold;     // :37
+                const bool tracking = act && was_found;
+                since += tracking ? 1 : 0;                                                 // :47
+                const bool take = first_hit || (tracking && inten > local_max);            // :50
+                local_max = take ? inten : local_max;
+                samp = take ? s[u] : samp;
+                hit_i = take ? (i + u) : hit_i;
+                found = found || first_hit;
+                const bool brk = tracking && (since >= P.lmip_max_samples || inten < local_max * P.lmip_fall_off);  // :58
+                finished = finished || brk;
+            }
+        } else if (COUNT) {
+            steps += active ? (uint32_t)(min(i + U, nsteps) - i) : 0u;
+        }
+    }
+
+    Hit h;
+    h.found = found; h.sample = samp; h.steps = steps;
+    const float hit_f = (float)hit_i;
+    h.offset = { hit_f * R.step.x, hit_f * R.step.y, hit_f * R.step.z };                    // raycast.wgsl:30
+    h.coord = { R.start.x + h.offset.x, R.start.y + h.offset.y, R.start.z + h.offset.z };   // :31
+    shade_and_store<NL>(P, o, frag, h);
+    if (COUNT && P.steps) P.steps[o] = h.steps;
+}
+
 template <int NL>
 hipError_t launch_nl(const MarchParams& p, int variant, hipStream_t stream) {
-    (void)variant;
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
-    if (p.steps)
-        hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    const bool simple = variant == 1 || p.density_all_bytes == 0;   // >= 4 GiB of rings: 64-bit addressing
+    if (simple) {
+        if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    } else if (variant == 2) {
+        if (p.steps) hipLaunchKernelGGL((march_batched<NL, 4, true>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_batched<NL, 4, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    } else {
+        if (p.steps) hipLaunchKernelGGL((march_batched<NL, 8, true>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_batched<NL, 8, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

@@ -64,6 +64,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->render_done = nullptr; c->render_pending = false;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
+    c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
 
     auto fail = [&](int code) { svr_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->render_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -74,23 +75,31 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         svr_set_error("svr_create: stream/event creation failed");
         return fail(SVR_ERR_HIP);
     }
+    size_t total = 0;
     for (int l = 0; l < num_lods; ++l) {
         LodStorage& L = c->lod[l];
         for (int a = 0; a < 3; ++a) L.ring[a] = lods[l].ring_dims[a];
         L.voxels = (size_t)L.ring[0] * (size_t)L.ring[1] * (size_t)L.ring[2];
         memset(&L.state, 0, sizeof(L.state));
         L.state.scale[0] = L.state.scale[1] = L.state.scale[2] = 1.0f;
-        if (hipMalloc((void**)&L.density, L.voxels * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&L.labels, L.voxels * sizeof(uint32_t)) != hipSuccess) {
-            svr_set_error("svr_create: out of device memory for ring textures");
-            return fail(SVR_ERR_NOMEM);
-        }
-        // zero-initialised textures (_wrapping_buffer.py:50-59)
-        if (hipMemsetAsync(L.density, 0, L.voxels * sizeof(float), c->upload_stream) != hipSuccess ||
-            hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream) != hipSuccess) {
-            svr_set_error("svr_create: memset failed");
-            return fail(SVR_ERR_HIP);
-        }
+        c->lod_base_bytes[l] = total;
+        total += (L.voxels * sizeof(float) + 255) & ~(size_t)255;
+    }
+    c->density_all_bytes = total;
+    // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
+    if (hipMalloc((void**)&c->density_all, total) != hipSuccess ||
+        hipMalloc((void**)&c->labels_all, total) != hipSuccess) {
+        svr_set_error("svr_create: out of device memory for ring textures");
+        return fail(SVR_ERR_NOMEM);
+    }
+    if (hipMemsetAsync(c->density_all, 0, total, c->upload_stream) != hipSuccess ||
+        hipMemsetAsync(c->labels_all, 0, total, c->upload_stream) != hipSuccess) {
+        svr_set_error("svr_create: memset failed");
+        return fail(SVR_ERR_HIP);
+    }
+    for (int l = 0; l < num_lods; ++l) {
+        c->lod[l].density = reinterpret_cast<float*>(reinterpret_cast<char*>(c->density_all) + c->lod_base_bytes[l]);
+        c->lod[l].labels = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->labels_all) + c->lod_base_bytes[l]);
     }
     if (hipEventRecord(c->uploads_published, c->upload_stream) != hipSuccess) return fail(SVR_ERR_HIP);
     c->have_published = true;
@@ -103,10 +112,8 @@ int svr_destroy(svr_ctx* c) {
     DeviceGuard guard(c->device);
     if (c->render_stream) (void)hipStreamSynchronize(c->render_stream);
     if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
-    for (int l = 0; l < SVR_MAX_LODS; ++l) {
-        if (c->lod[l].density) (void)hipFree(c->lod[l].density);
-        if (c->lod[l].labels) (void)hipFree(c->lod[l].labels);
-    }
+    if (c->density_all) (void)hipFree(c->density_all);
+    if (c->labels_all) (void)hipFree(c->labels_all);
     for (auto& s : c->slot) {
         if (s.host) (void)hipHostFree(s.host);
         if (s.dev) (void)hipFree(s.dev);
@@ -386,8 +393,13 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             Q.ring[a] = (uint32_t)L.ring[a];
             Q.wrap0[a] = (uint32_t)(L.state.offset[a] - floor_div(L.state.offset[a], L.ring[a]) * L.ring[a]);
             Q.scale[a] = L.state.scale[a];
+            Q.addw[a] = (int32_t)Q.wrap0[a] - Q.off[a];
         }
+        Q.rx4 = Q.ring[0] * 4u;
+        Q.base_bytes = (uint32_t)c->lod_base_bytes[l];
     }
+    P.density_all = c->density_all;
+    P.density_all_bytes = c->density_all_bytes < ((size_t)1 << 32) ? (uint32_t)c->density_all_bytes : 0u;
     return SVR_OK;
 }
 

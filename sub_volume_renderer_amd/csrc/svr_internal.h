@@ -24,7 +24,9 @@ struct LodParams {
     uint32_t wrap0[3];         // off - floor(off/ring)*ring  (ring slot of the ROI's first voxel)
     uint32_t ring[3];          // ring extent
     float    scale[3];         // scale_factor
-    uint32_t pad_;
+    uint32_t base_bytes;       // byte offset of this LOD's density ring inside MarchParams::density_all
+    int32_t  addw[3];          // wrap0 - off: ring slot = wrap(ic + addw)
+    uint32_t rx4;              // ring[0] * 4 (row pitch in bytes)
 };
 
 struct MarchParams {
@@ -50,6 +52,10 @@ struct MarchParams {
     uint32_t* label;
     uint8_t*  flags;
     uint32_t* steps;
+    // all LOD density rings live in ONE allocation so a single buffer resource
+    // (32-bit byte offsets, hardware range check) addresses every LOD
+    const float* density_all;
+    uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
     // block -> tile mapping
     int32_t tiles_x, tiles_y;
     LodParams lod[SVR_MAX_LODS];
@@ -74,6 +80,10 @@ struct svr_ctx {
     int device;
     int num_lods;
     LodStorage lod[SVR_MAX_LODS];
+    float*    density_all;           // one allocation, LOD rings at 256-byte aligned offsets
+    uint32_t* labels_all;
+    size_t    density_all_bytes;
+    size_t    lod_base_bytes[SVR_MAX_LODS];
     hipStream_t render_stream;
     hipStream_t upload_stream;
     hipEvent_t  uploads_published;   // recorded on upload_stream by svr_publish_uploads
