@@ -179,8 +179,12 @@ int  svr_clear_lod(svr_ctx* ctx, int lod);
  * own render stream).  Asynchronous. */
 int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
                 const svr_outputs* out, void* stream);
-/* kernel variant selector for A/B measurement: 0 = default (tuned),
- * 1 = straightforward one-thread-per-pixel global-memory march */
+/* kernel variant selector for A/B measurement (results are identical for every value):
+ * bits 0-3  kernel: 0 = default batched march, 1 = straightforward one-load-per-step march,
+ *           2 = batched march with 4 loads in flight
+ * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
+ * bit  8    disable the per-lane iteration skew
+ * bit  9    disable the lane->pixel shear along the projected x axis */
 int  svr_set_variant(svr_ctx* ctx, int variant);
 
 /* ---- multi-GPU helper: scatter a rank-major gathered stripe buffer back

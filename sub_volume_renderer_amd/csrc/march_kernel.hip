@@ -250,21 +250,27 @@ __global__ __launch_bounds__(256) void march_simple(const MarchParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// Variant 0 (default): batched march.
+// Variant 0 (default): span march.
 //
 // Exactness argument.  For one ray and one axis, the voxel index the reference
 // computes at iteration i,
 //     ic(i) = i32( ((start + f32(i)*step) * size) * scale )        (raycast.wgsl:30-31,
 //                                                                   sample_vol.wgsl:6-8,17)
 // is a composition of monotone functions of i (IEEE rounding is monotone), so it is
-// monotone in i.  Hence "voxel i lies in LOD l's ROI" holds on ONE contiguous
-// iteration interval [A_l, B_l), whose ends are found exactly by evaluating that
-// same f32 chain (first_true below).  The cascade of sample_vol.wgsl:51-63 then is
-// "smallest l with A_l <= i < B_l".  With the intervals known, a wave whose lanes
-// are all inside the same LOD for a whole batch of U steps needs no bounds tests,
-// computes U texel offsets, issues U independent buffer loads (hardware range
-// check returns 0 for "no LOD"), and only then runs the sequential LMIP state
-// machine — skipped entirely while no lane has reached the threshold.
+// monotone in i.  Therefore, per LOD l and axis:
+//   * "ic lies in the ROI" holds on ONE contiguous iteration interval; intersecting the
+//     three axes gives [A_l, B_l), and the cascade of sample_vol.wgsl:51-63 is
+//     "smallest l with A_l <= i < B_l";
+//   * the ring wrap  slot = (ic + addw) mod ring  (sample_vol.wgsl:22) changes its
+//     constant at most once, at an iteration C_{l,axis}.
+// All these iterations are found EXACTLY by evaluating that same f32 chain
+// (first_cross).  Between two consecutive events a lane's texel address is
+//     ((iz*Ry + iy)*Rx + ix)*4 + Kc        with a per-lane constant Kc,
+// so the hot loop has no bounds tests, no cascade and no modulo; it computes U
+// offsets, issues U independent buffer loads (hardware range check returns 0 where
+// no LOD holds the voxel) and only then runs the sequential LMIP state machine —
+// skipped entirely while no lane has reached the threshold.  Batches that contain an
+// event for some lane take the general path, which evaluates every sample exactly.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int axis_voxel(int i, float start, float step, float size, float scale) {
     float off = (float)i * step;          // raycast.wgsl:30  (iter is an exact integer-valued f32)
@@ -274,40 +280,28 @@ __device__ __forceinline__ int axis_voxel(int i, float start, float step, float 
     return (int)sd;                       // :17 vec3<i32>()
 }
 
-// smallest i in [0, n] with pred(i), for a monotone (false.. true..) predicate
-template <class Pred>
-__device__ __forceinline__ int first_true(float guess, int n, Pred pred) {
-    int i = (int)fminf(fmaxf(guess, 0.0f), (float)n);
-    while (i > 0 && pred(i - 1)) --i;
-    while (i < n && !pred(i)) ++i;
-    return i;
+// First iteration j in [0, n] at which the (monotone) voxel index has crossed `thresh`
+// in its direction of travel: ic(j) >= thresh for step > 0, ic(j) < thresh for step < 0.
+// A zero step never crosses: returns 0 if the condition already holds, else n.
+__device__ __forceinline__ int first_cross(int n, float start, float step, float size, float scale, int thresh) {
+    const bool inc = step > 0.0f;
+    auto pred = [&](int j) {
+        const int v = axis_voxel(j, start, step, size, scale);
+        return inc ? v >= thresh : v < thresh;
+    };
+    if (!(step > 0.0f) && !(step < 0.0f)) return pred(0) ? 0 : n;
+    const float guess = ceilf(((float)thresh / (size * scale) - start) / step);
+    int j = (int)fminf(fmaxf(guess, 0.0f), (float)n);
+#pragma nounroll
+    while (j > 0 && pred(j - 1)) --j;
+#pragma nounroll
+    while (j < n && !pred(j)) ++j;
+    return j;
 }
 
-// iterations for which lo <= ic(i) < hi on one axis: [enter, exit)
-__device__ __forceinline__ void axis_interval(int n, float start, float step, float size, float scale,
-                                              int lo, int hi, int& enter, int& exit) {
-    auto g = [&](int i) { return axis_voxel(i, start, step, size, scale); };
-    if (!(step > 0.0f) && !(step < 0.0f)) {           // zero (or NaN) step: constant along the ray
-        const int v = g(0);
-        const bool in = lo <= v && v < hi;
-        enter = 0; exit = in ? n : 0;
-        return;
-    }
-    const float k = size * scale;
-    const float glo = ceilf(((float)lo / k - start) / step);
-    const float ghi = ceilf(((float)hi / k - start) / step);
-    if (step > 0.0f) {
-        enter = first_true(glo, n, [&](int i) { return g(i) >= lo; });
-        exit  = first_true(ghi, n, [&](int i) { return g(i) >= hi; });
-    } else {
-        enter = first_true(ghi, n, [&](int i) { return g(i) < hi; });
-        exit  = first_true(glo, n, [&](int i) { return g(i) < lo; });
-    }
-}
-
-// byte offset of the texel under data coord d inside MarchParams::density_all, for a
-// voxel KNOWN to lie in LOD L's ROI (no bounds test)
-__device__ __forceinline__ uint32_t lod_offset_inside(const LodParams& L, float dx, float dy, float dz) {
+// Byte offset (inside MarchParams::density_all) of the texel under data coord d for a
+// voxel KNOWN to lie in LOD L's ROI; general form with the explicit ring wrap.
+__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodParams& L, float dx, float dy, float dz) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -315,41 +309,60 @@ __device__ __forceinline__ uint32_t lod_offset_inside(const LodParams& L, float 
     wx = min(wx, wx - L.ring[0]);
     wy = min(wy, wy - L.ring[1]);
     wz = min(wz, wz - L.ring[2]);
-    return (wz * L.ring[1] + wy) * L.rx4 + L.base_bytes + (wx << 2);
+    return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << 2);
 }
 
+// Per-ray event table of one LOD
+struct LodEvents {
+    int a, b;            // ROI interval [a, b)
+    int cx, cy, cz;      // wrap-constant change iterations per axis
+};
+
 template <int NL, int U, bool COUNT>
-__global__ __launch_bounds__(256) void march_batched(const MarchParams P) {
+__global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     const int nblocks = P.tiles_x * P.tiles_y;
-    const int t = xcd_remap((int)blockIdx.x, nblocks);
-    const int tile_x = t % P.tiles_x, tile_y = t / P.tiles_x;
+    const int tb = xcd_remap((int)blockIdx.x, nblocks);
+    const int tile_x = tb % P.tiles_x, tile_y = tb / P.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int r = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (c >= P.frame.out_w || r >= P.frame.out_h) return;
+    // wave tile = (1 << lw) x (64 >> lw) pixels; a block is 2 x 2 wave tiles
+    const int lw = P.tile_log2w;
+    const int c = ((tile_x * 2 + (wave & 1)) << lw) + (lane & ((1 << lw) - 1));
+    const int r = ((tile_y * 2 + (wave >> 1)) << (6 - lw)) + (lane >> lw);
+    const bool inside = c < P.frame.out_w && r < P.frame.out_h;
     const size_t o = (size_t)r * (size_t)P.frame.out_w + (size_t)c;
     const int x = P.frame.x0 + c;
     const int y = P.frame.y0 + (r / P.frame.band_h) * P.frame.band_pitch + (r % P.frame.band_h);
 
     Ray R;
     R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
-    const bool frag = (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
+    const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
     const int nsteps = frag ? R.nsteps : 0;
 
-    // exact per-LOD iteration intervals
-    int A[NL], B[NL];
+    // ---- exact per-LOD event iterations
+    LodEvents ev[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        A[l] = 0; B[l] = 0;
-        if (frag) {
-            const LodParams& L = P.lod[l];
-            int e0, x0, e1, x1, e2, x2;
-            axis_interval(nsteps, R.start.x, R.step.x, P.size[0], L.scale[0], L.off[0], L.off[0] + (int)L.shape[0], e0, x0);
-            axis_interval(nsteps, R.start.y, R.step.y, P.size[1], L.scale[1], L.off[1], L.off[1] + (int)L.shape[1], e1, x1);
-            axis_interval(nsteps, R.start.z, R.step.z, P.size[2], L.scale[2], L.off[2], L.off[2] + (int)L.shape[2], e2, x2);
-            const int a = max(e0, max(e1, e2)), b = min(x0, min(x1, x2));
-            if (a < b) { A[l] = a; B[l] = b; }
+        const LodParams& L = P.lod[l];
+        int a = 0, b = nsteps, cr[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float st = ax == 0 ? R.start.x : (ax == 1 ? R.start.y : R.start.z);
+            const float sp = ax == 0 ? R.step.x : (ax == 1 ? R.step.y : R.step.z);
+            const int lo = L.off[ax], hi = L.off[ax] + (int)L.shape[ax];
+            const int jlo = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], lo);
+            const int jhi = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], hi);
+            // increasing: inside on [jlo, jhi); decreasing: inside on [jhi, jlo)
+            const bool inc = sp > 0.0f;
+            int en = inc ? jlo : jhi, ex = inc ? jhi : jlo;
+            if (!(sp > 0.0f) && !(sp < 0.0f)) {            // constant index: inside always or never
+                const int v = axis_voxel(0, st, sp, P.size[ax], L.scale[ax]);
+                en = 0; ex = (lo <= v && v < hi) ? nsteps : 0;
+            }
+            a = max(a, en); b = min(b, ex);
+            cr[ax] = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], (int)L.ring[ax] - L.addw[ax]);
         }
+        if (a >= b || L.shape[0] == 0) { a = 0; b = 0; }
+        ev[l].a = a; ev[l].b = b; ev[l].cx = cr[0]; ev[l].cy = cr[1]; ev[l].cz = cr[2];
     }
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -360,83 +373,117 @@ __global__ __launch_bounds__(256) void march_batched(const MarchParams P) {
     int hit_i = 0, since = 0;
     uint32_t steps = 0;
 
-    for (int i = 0;; i += U) {
-        const bool active = !finished && i < nsteps;
-        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        float s[U];
-        bool valid[U];
-        if (active) {
-            const int iend = min(i + U, nsteps);
-            // which LOD serves this whole batch for this lane?  NL = "none", -1 = mixed
-            int code = NL;
-            bool settled = false;
+    // span state: iterations [.., E) use LOD `code` (NL = none) with address constant Kc
+    int code = NL, E = 0;
+    uint32_t Kc = 0xFFFFFFFFu;
+
+    for (int n = 0;; n += U) {                       // n is wave-uniform: every ray starts at iteration 0
+        const bool alive = !finished && n < nsteps;
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // (alive_mask below is therefore non-zero)
+
+        // ---- span refresh for the lanes whose span has ended
+        if (__builtin_amdgcn_ballot_w64(alive && n >= E) != 0) {
+            if (alive && n >= E) {
+                code = NL; E = nsteps; Kc = 0xFFFFFFFFu;
+                bool settled = false;
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const bool inb = i >= A[l] && iend <= B[l];
-                const bool outb = iend <= A[l] || i >= B[l];
-                if (!settled) {
-                    if (inb) { code = l; settled = true; }
-                    else if (!outb) { code = -1; settled = true; }
+                for (int l = 0; l < NL; ++l) {
+                    const bool in = !settled && n >= ev[l].a && n < ev[l].b;
+                    if (in) {
+                        const LodParams& L = P.lod[l];
+                        code = l;
+                        E = min(E, ev[l].b);
+                        // wrap constants in force at iteration n, and when they change next
+                        const bool px = (n >= ev[l].cx) == (R.step.x > 0.0f);   // slot = ic + addw - ring ?
+                        const bool py = (n >= ev[l].cy) == (R.step.y > 0.0f);
+                        const bool pz = (n >= ev[l].cz) == (R.step.z > 0.0f);
+                        const uint32_t kx = (uint32_t)L.addw[0] - (px ? L.ring[0] : 0u);
+                        const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
+                        const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
+                        Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << 2) + L.base_bytes;   // mod 2^32
+                        if (ev[l].cx > n) E = min(E, ev[l].cx);
+                        if (ev[l].cy > n) E = min(E, ev[l].cy);
+                        if (ev[l].cz > n) E = min(E, ev[l].cz);
+                    } else if (!settled && ev[l].a > n) {
+                        E = min(E, ev[l].a);                 // a finer LOD takes over there
+                    }
+                    settled = settled || in;
                 }
             }
-            const int first = __builtin_amdgcn_readfirstlane(code);
-            const bool uniform = first >= 0 && __builtin_amdgcn_ballot_w64(code != first) == 0;
-            uint32_t off[U];
+        }
+
+        float s[U];
+        // ---- fast batch: every live lane is inside one span of the same LOD for all U samples
+        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+        const int first = __builtin_amdgcn_readlane(code, (int)__builtin_ctzll(alive_mask));
+        const bool lane_ok = !alive || (code == first && n + U <= E);
+        const bool fast = __builtin_amdgcn_ballot_w64(!lane_ok) == 0;
+        const float basef = (float)n;
+        if (fast) {
+            if (first == NL) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) { off[u] = 0xFFFFFFFFu; valid[u] = (i + u) < nsteps; }
-            const float basef = (float)i;
-            if (uniform) {
-                if (first < NL) {
+                for (int u = 0; u < U; ++u) s[u] = 0.0f;          // no LOD holds these voxels (sample_vol.wgsl:62)
+            }
 #pragma unroll
-                    for (int l = 0; l < NL; ++l) {
-                        if (first == l) {
+            for (int l = 0; l < NL; ++l) {
+                if (first == l) {
+                    const LodParams& L = P.lod[l];
+                    uint32_t off[U];
 #pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                const float iter = basef + (float)u;
-                                const float cx = R.start.x + iter * R.step.x;
-                                const float cy = R.start.y + iter * R.step.y;
-                                const float cz = R.start.z + iter * R.step.z;
-                                off[u] = lod_offset_inside(P.lod[l], cx * P.size[0], cy * P.size[1], cz * P.size[2]);
-                            }
-                        }
+                    for (int u = 0; u < U; ++u) {
+                        const float iter = basef + (float)u;
+                        const float dx = ((R.start.x + iter * R.step.x) * P.size[0]) * L.scale[0];
+                        const float dy = ((R.start.y + iter * R.step.y) * P.size[1]) * L.scale[1];
+                        const float dz = ((R.start.z + iter * R.step.z) * P.size[2]) * L.scale[2];
+                        const uint32_t row = __umul24((uint32_t)(int)dz, L.ring[1]) + (uint32_t)(int)dy;
+                        off[u] = __umul24(row, L.rx4) + Kc + ((uint32_t)(int)dx << 2);
+                    }
+                    if (alive) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[u], 0, 0));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) s[u] = 0.0f;
                     }
                 }
-            } else {
+            }
+        } else {
+            // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
+            uint32_t off[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float iter = basef + (float)u;
-                    const float dx = (R.start.x + iter * R.step.x) * P.size[0];
-                    const float dy = (R.start.y + iter * R.step.y) * P.size[1];
-                    const float dz = (R.start.z + iter * R.step.z) * P.size[2];
-                    bool done = false;
+            for (int u = 0; u < U; ++u) {
+                off[u] = 0xFFFFFFFFu;
+                const float iter = basef + (float)u;
+                const float dx = (R.start.x + iter * R.step.x) * P.size[0];
+                const float dy = (R.start.y + iter * R.step.y) * P.size[1];
+                const float dz = (R.start.z + iter * R.step.z) * P.size[2];
+                bool done = !alive || (n + u) >= nsteps;
 #pragma unroll
-                    for (int l = 0; l < NL; ++l) {
-                        const bool sel = !done && (i + u) >= A[l] && (i + u) < B[l];
-                        if (__builtin_amdgcn_ballot_w64(sel) != 0) {
-                            const uint32_t ofs = lod_offset_inside(P.lod[l], dx, dy, dz);
-                            off[u] = sel ? ofs : off[u];
-                        }
-                        done = done || sel;
+                for (int l = 0; l < NL; ++l) {
+                    const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
+                    if (__builtin_amdgcn_ballot_w64(sel) != 0) {
+                        const uint32_t ofs = lod_offset_wrapped(P.lod[l], dx, dy, dz);
+                        off[u] = sel ? ofs : off[u];
                     }
+                    done = done || sel;
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[u], 0, 0));
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { s[u] = 0.f; valid[u] = false; }
         }
 
-        // LMIP state machine (raycast.wgsl:35-61); skipped while nothing can change
+        // ---- LMIP state machine (raycast.wgsl:35-61); skipped while nothing can change
+        const bool tail = n + U > nsteps;                       // some samples of this lane do not exist
         float m = -1.0f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) m = fmaxf(m, valid[u] ? fabsf(s[u]) : -1.0f);
-        const bool need = active && (found || m >= P.lmip_threshold);
+        for (int u = 0; u < U; ++u) m = fmaxf(m, (tail && (n + u) >= nsteps) ? -1.0f : fabsf(s[u]));
+        const bool need = alive && (found || m >= P.lmip_threshold);
         if (__builtin_amdgcn_ballot_w64(need) != 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool act = active && valid[u] && !finished;
+                const bool act = alive && (n + u) < nsteps && !finished;
                 const float inten = fabsf(s[u]);
                 if (COUNT) steps += act ? 1u : 0u;
                 const bool was_found = found;
@@ -446,13 +493,13 @@ __global__ __launch_bounds__(256) void march_batched(const MarchParams P) {
                 const bool take = first_hit || (tracking && inten > local_max);            // :50
                 local_max = take ? inten : local_max;
                 samp = take ? s[u] : samp;
-                hit_i = take ? (i + u) : hit_i;
+                hit_i = take ? (n + u) : hit_i;
                 found = found || first_hit;
                 const bool brk = tracking && (since >= P.lmip_max_samples || inten < local_max * P.lmip_fall_off);  // :58
                 finished = finished || brk;
             }
         } else if (COUNT) {
-            steps += active ? (uint32_t)(min(i + U, nsteps) - i) : 0u;
+            steps += alive ? (uint32_t)(min(n + U, nsteps) - n) : 0u;
         }
     }
 
@@ -461,40 +508,44 @@ __global__ __launch_bounds__(256) void march_batched(const MarchParams P) {
     const float hit_f = (float)hit_i;
     h.offset = { hit_f * R.step.x, hit_f * R.step.y, hit_f * R.step.z };                    // raycast.wgsl:30
     h.coord = { R.start.x + h.offset.x, R.start.y + h.offset.y, R.start.z + h.offset.z };   // :31
-    shade_and_store<NL>(P, o, frag, h);
-    if (COUNT && P.steps) P.steps[o] = h.steps;
+    if (inside) {
+        // the epilogue re-reads its (cold) uniforms through a laundered kernarg pointer so that
+        // they are not kept live in SGPRs across the march loop
+#if defined(__HIP_DEVICE_COMPILE__)
+        const MarchParams* Pk = (const MarchParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(Pk));
+#else
+        const MarchParams* Pk = &P;
+#endif
+        shade_and_store<NL>(*Pk, o, frag, h);
+        if (COUNT && Pk->steps) Pk->steps[o] = h.steps;
+    }
 }
 
 template <int NL>
-hipError_t launch_nl(const MarchParams& p, int variant, hipStream_t stream) {
+hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
-    const bool simple = variant == 1 || p.density_all_bytes == 0;   // >= 4 GiB of rings: 64-bit addressing
+    const bool simple = kind == 1 || p.density_all_bytes == 0;   // >= 4 GiB of rings: 64-bit addressing
     if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
-    } else if (variant == 2) {
-        if (p.steps) hipLaunchKernelGGL((march_batched<NL, 4, true>), dim3(nblocks), dim3(256), 0, stream, p);
-        else         hipLaunchKernelGGL((march_batched<NL, 4, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
-        if (p.steps) hipLaunchKernelGGL((march_batched<NL, 8, true>), dim3(nblocks), dim3(256), 0, stream, p);
-        else         hipLaunchKernelGGL((march_batched<NL, 8, false>), dim3(nblocks), dim3(256), 0, stream, p);
+        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_span<NL, 8, false>), dim3(nblocks), dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t svr_launch_march(const MarchParams& p, int variant, hipStream_t stream) {
-    switch (p.num_lods) {
-        case 1: return launch_nl<1>(p, variant, stream);
-        case 2: return launch_nl<2>(p, variant, stream);
-        case 3: return launch_nl<3>(p, variant, stream);
-        case 4: return launch_nl<4>(p, variant, stream);
-        case 5: return launch_nl<5>(p, variant, stream);
-        case 6: return launch_nl<6>(p, variant, stream);
-        case 7: return launch_nl<7>(p, variant, stream);
-        case 8: return launch_nl<8>(p, variant, stream);
-        default: return hipErrorInvalidValue;
-    }
+// One translation unit per LOD count (compiled in parallel with -DSVR_NL=k): the
+// reference specialises its shader on num_scales the same way (_shader.py:73).
+#ifndef SVR_NL
+#error "compile with -DSVR_NL=<number of LODs>"
+#endif
+#define SVR_CAT2(a, b) a##b
+#define SVR_CAT(a, b) SVR_CAT2(a, b)
+hipError_t SVR_CAT(svr_launch_march_nl, SVR_NL)(const MarchParams& p, int kind, hipStream_t stream) {
+    return launch_nl<SVR_NL>(p, kind, stream);
 }

@@ -382,7 +382,22 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
     P.num_lods = c->num_lods;
     P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
-    P.tiles_x = (fr->out_w + 15) / 16; P.tiles_y = (fr->out_h + 15) / 16;
+    // variant: bits 0-3 kernel kind (0 batched U=8, 1 simple, 2 batched U=4), bits 4-7 = 1 + log2 of the
+    // wave tile width (0 = default 8x8), bit 8 = disable the iteration skew
+    int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;
+    if (lw > 6) lw = 6;
+    if ((c->variant & 15) == 1) lw = 3;                       // the simple kernel is 8x8 only
+    P.tile_log2w = lw;
+    P.skew = (c->variant & 256) ? 0 : 1;
+    P.shear = (c->variant & 512) ? 0 : 1;
+    {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
+        const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
+        float wx[4];
+        mat_vec4(cam->world, ex, wx);
+        mat_vec4(P.pc, wx, P.xdir);
+    }
+    const int bw = 2 << lw, bh = 2 * (64 >> lw);
+    P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     for (int l = 0; l < c->num_lods; ++l) {
         const LodStorage& L = c->lod[l];
         LodParams& Q = P.lod[l];
@@ -410,7 +425,7 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     DeviceGuard guard(c->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->render_stream;
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
-    SVR_HIP_TRY(svr_launch_march(P, c->variant, s));
+    SVR_HIP_TRY(svr_launch_march(P, c->variant & 15, s));
     SVR_HIP_TRY(hipEventRecord(c->render_done, s));
     c->render_pending = true;
     return SVR_OK;
@@ -426,7 +441,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
     hipStream_t s = c->render_stream;
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
-    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, c->variant, s));
+    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, c->variant & 15, s));
     SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
     SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
     float ms = 0.f;

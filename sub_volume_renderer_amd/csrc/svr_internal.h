@@ -58,6 +58,10 @@ struct MarchParams {
     uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
     // block -> tile mapping
     int32_t tiles_x, tiles_y;
+    int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
+    int32_t skew;                  // 1: per-lane iteration skew (see march_kernel.hip)
+    int32_t shear;                 // 1: lanes follow the screen direction of the volume's x axis
+    float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)
     LodParams lod[SVR_MAX_LODS];
 };
 
