@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define SVR_MAX_LODS 8
-#define SVR_ABI_VERSION 1
+#define SVR_ABI_VERSION 2
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -49,6 +49,11 @@ typedef enum svr_dtype {
  * extent ring_dims (shader order), zero-initialised. */
 typedef struct svr_lod_desc {
     int32_t ring_dims[3];          /* (x, y, z) voxels = reversed shape_in_pixels */
+    int32_t density_storage;       /* SVR_F32: the reference's r32float texture.  SVR_U8: store the
+                                      density ring as bytes — allowed only when every upload's
+                                      source dtype is uint8, so that texel values (0..255, exact in
+                                      f32) and therefore all results are identical; 4x less HBM / L2 /
+                                      LDS per voxel.  All LODs of a context use the same storage. */
 } svr_lod_desc;
 
 /* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.
@@ -180,11 +185,9 @@ int  svr_clear_lod(svr_ctx* ctx, int lod);
 int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
                 const svr_outputs* out, void* stream);
 /* kernel variant selector for A/B measurement (results are identical for every value):
- * bits 0-3  kernel: 0 = default batched march, 1 = straightforward one-load-per-step march,
- *           2 = batched march with 4 loads in flight
+ * bits 0-3  kernel: 0 = default span march, 1 = straightforward one-load-per-step march
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
- * bit  8    disable the per-lane iteration skew
- * bit  9    disable the lane->pixel shear along the projected x axis */
+ * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave heuristic; u8 rings only) */
 int  svr_set_variant(svr_ctx* ctx, int variant);
 
 /* ---- multi-GPU helper: scatter a rank-major gathered stripe buffer back

@@ -20,7 +20,7 @@ from . import _native as N
 from ._geometry import Coordinate, Roi
 from ._material import SubVolumeMaterial
 from ._transform import _HasWorld
-from ._wrapping_buffer import DeviceRings, WrappingBuffer
+from ._wrapping_buffer import DeviceRings, WrappingBuffer, native_density_storage
 
 
 @dataclass
@@ -75,6 +75,7 @@ class SubVolume(_HasWorld):
         chunk_shape_in_pixels=None,
         *,
         device: int | None = None,
+        ring_storage: str = "native",
     ):
         super().__init__()
         base_data = data_segmentation_pairs[0][0]
@@ -115,6 +116,9 @@ class SubVolume(_HasWorld):
         self._rings = DeviceRings(
             [tuple(Coordinate(b) * Coordinate(c)) for b, c in zip(buffer_shapes, chunk_shapes)],
             device=device,
+            # "native": byte rings when every density source is uint8 (identical results, 4x less
+            # memory traffic); "float32": always the reference's r32float layout
+            density_storage=native_density_storage([d for d, _ in data_segmentation_pairs], ring_storage),
         )
         self.wrapping_buffers: list[WrappingBuffer] = []
         for i, (scale_data, scale_segmentations) in enumerate(data_segmentation_pairs):

@@ -33,10 +33,15 @@ from ._geometry import Coordinate, Roi
 class DeviceRings:
     """The ``svr_ctx`` that owns the ring textures of all LODs of one volume."""
 
-    def __init__(self, ring_shapes, device: int | None = None):
+    def __init__(self, ring_shapes, device: int | None = None, density_storage: str = "float32"):
         # ring_shapes: numpy-order voxel extents, one per LOD
         self.ring_shapes = [tuple(int(v) for v in s) for s in ring_shapes]
         self.device = device
+        # "float32": the reference's r32float texture.  "uint8": byte rings for uint8 sources
+        # (values 0..255 are exact in f32, so every sample and result is identical)
+        if density_storage not in ("float32", "uint8"):
+            raise ValueError("density_storage must be 'float32' or 'uint8'")
+        self.density_storage = density_storage
         self._handle = None
 
     @property
@@ -46,6 +51,7 @@ class DeviceRings:
             descs = (N.LodDesc * len(self.ring_shapes))()
             for d, s in zip(descs, self.ring_shapes):
                 d.ring_dims[:] = s[::-1]
+                d.density_storage = N.SVR_U8 if self.density_storage == "uint8" else N.SVR_F32
             device = self.device
             if device is None:
                 import torch
@@ -114,6 +120,19 @@ def _is_device_tensor(a) -> bool:
     return type(a).__module__.split(".")[0] == "torch" and bool(getattr(a, "is_cuda", False))
 
 
+def native_density_storage(arrays, ring_storage: str = "native") -> str:
+    """Ring element type for a set of backing density arrays: bytes when every source is uint8."""
+    if ring_storage not in ("native", "float32"):
+        raise ValueError("ring_storage must be 'native' or 'float32'")
+    if ring_storage == "float32":
+        return "float32"
+    for a in arrays:
+        dt = str(getattr(a, "dtype", "")).replace("torch.", "")
+        if dt != "uint8":
+            return "float32"
+    return "uint8"
+
+
 # ---------------------------------------------------------------------------
 class WrappingBuffer:
     """A buffer for volumetric data that wraps around like a 3D ring."""
@@ -132,9 +151,11 @@ class WrappingBuffer:
         chunk_shape_in_pixels=None,
         scale_factor=(1.0, 1.0, 1.0),
         *,
+        ring_storage: str = "native",
         _rings: DeviceRings | None = None,
         _lod: int = 0,
     ):
+        self._ring_storage = ring_storage
         self.backing_data = backing_data
         self.segmentations = segmentations
         self.shape_in_chunks = Coordinate(shape_in_chunks)
@@ -163,7 +184,8 @@ class WrappingBuffer:
     @property
     def rings(self) -> DeviceRings:
         if self._rings is None:
-            self._rings = DeviceRings([tuple(self.shape_in_pixels)])
+            self._rings = DeviceRings([tuple(self.shape_in_pixels)],
+                                      density_storage=native_density_storage([self.backing_data], self._ring_storage))
             self._lod = 0
         return self._rings
 

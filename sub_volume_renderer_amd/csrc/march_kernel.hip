@@ -56,7 +56,9 @@ __device__ __forceinline__ float sample_density(const MarchParams& P, float cx, 
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         size_t idx;
-        if (lod_texel(P.lod[l], dx, dy, dz, idx)) return P.lod[l].density[idx];
+        if (lod_texel(P.lod[l], dx, dy, dz, idx))
+            return P.density_u8 ? (float)static_cast<const uint8_t*>(P.lod[l].density)[idx]
+                                : static_cast<const float*>(P.lod[l].density)[idx];
     }
     return 0.0f;
 }
@@ -301,6 +303,7 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
 
 // Byte offset (inside MarchParams::density_all) of the texel under data coord d for a
 // voxel KNOWN to lie in LOD L's ROI; general form with the explicit ring wrap.
+template <int ESH>
 __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodParams& L, float dx, float dy, float dz) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
@@ -309,7 +312,71 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodParams& L, float
     wx = min(wx, wx - L.ring[0]);
     wy = min(wy, wy - L.ring[1]);
     wz = min(wz, wz - L.ring[2]);
-    return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << 2);
+    return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
+}
+
+// texel fetch through the range-checked buffer resource: f32 (ESH = 2) or u8 (ESH = 0) storage
+template <int ESH>
+__device__ __forceinline__ float fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
+    if (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+    return (float)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, 0, 0);
+}
+
+// a*b + c on the 24-bit integer multiplier (one full-rate-class VALU op); a, b < 2^24
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t shl_add(uint32_t a, uint32_t sh, uint32_t c) {   // (a << sh) + c
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(sh), "v"(c));
+    return r;
+}
+template <int SH>
+__device__ __forceinline__ uint32_t shl_add_c(uint32_t a, uint32_t c) {                // (a << SH) + c
+    if (SH == 0) return a + c;
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
+    return r;
+}
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+// wave64 reduction of two packed 16-bit minima at once (v_pk_min_i16): returns (min lo, min hi)
+__device__ __forceinline__ short2_t wave_min2(short2_t v) {
+#define SVR_DPP_STEP2(ctrl, rmask)                                                                          \
+    {                                                                                                       \
+        const int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),  \
+                                                   ctrl, rmask, 0xF, false);                                \
+        v = __builtin_elementwise_min(v, __builtin_bit_cast(short2_t, t_));                                 \
+    }
+    SVR_DPP_STEP2(0xB1, 0xF)
+    SVR_DPP_STEP2(0x4E, 0xF)
+    SVR_DPP_STEP2(0x141, 0xF)
+    SVR_DPP_STEP2(0x140, 0xF)
+    SVR_DPP_STEP2(0x142, 0xA)
+    SVR_DPP_STEP2(0x143, 0xC)
+#undef SVR_DPP_STEP2
+    return __builtin_bit_cast(short2_t, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// wave64 min / max of an int via DPP (no LDS traffic); result is wave-uniform
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce(int v) {
+#define SVR_DPP_STEP(ctrl, rmask)                                                   \
+    {                                                                               \
+        const int t_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xF, false);  \
+        v = MAX ? max(v, t_) : min(v, t_);                                          \
+    }
+    SVR_DPP_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    SVR_DPP_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    SVR_DPP_STEP(0x141, 0xF)   // row_half_mirror
+    SVR_DPP_STEP(0x140, 0xF)   // row_mirror: every lane of a row now holds the row result
+    SVR_DPP_STEP(0x142, 0xA)   // row_bcast15 into rows 1 and 3
+    SVR_DPP_STEP(0x143, 0xC)   // row_bcast31 into rows 2 and 3
+#undef SVR_DPP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Per-ray event table of one LOD
@@ -318,8 +385,13 @@ struct LodEvents {
     int cx, cy, cz;      // wrap-constant change iterations per axis
 };
 
-template <int NL, int U, bool COUNT>
+// LDS brick geometry (u8 storage): one private region per wave
+constexpr int kSlab = 16;              // iterations per brick
+constexpr int kBrickBytes = 8192;      // per wave; 4 waves per block -> 32 KiB per block
+
+template <int NL, int U, bool COUNT, int ESH>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[ESH == 0 ? 4 * kBrickBytes : 16];
     const int nblocks = P.tiles_x * P.tiles_y;
     const int tb = xcd_remap((int)blockIdx.x, nblocks);
     const int tile_x = tb % P.tiles_x, tile_y = tb / P.tiles_x;
@@ -366,20 +438,65 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     }
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
+        const_cast<void*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
 
     bool found = false, finished = false;
     float local_max = 0.f, samp = 0.f;
     int hit_i = 0, since = 0;
     uint32_t steps = 0;
 
+    // LMIP state machine over one batch of U samples starting at iteration nb (raycast.wgsl:35-61).
+    // `live`: this lane executes the batch; `tail`: some of its samples may lie beyond nsteps.
+    // Skipped entirely while no lane can change state (nothing found yet, nothing >= threshold).
+    auto lmip_batch = [&](const float (&sv)[U], int nb, bool live, bool tail) {
+        float m = -1.0f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m = fmaxf(m, (tail && (nb + u) >= nsteps) ? -1.0f : fabsf(sv[u]));
+        const bool need = live && (found || m >= P.lmip_threshold);
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool act = live && !finished && (!tail || (nb + u) < nsteps);
+                const float inten = fabsf(sv[u]);
+                if (COUNT) steps += act ? 1u : 0u;
+                const bool was_found = found;
+                const bool first_hit = act && !was_found && inten >= P.lmip_threshold;     // :37
+                const bool tracking = act && was_found;
+                since += tracking ? 1 : 0;                                                 // :47
+                const bool take = first_hit || (tracking && inten > local_max);            // :50
+                local_max = take ? inten : local_max;
+                samp = take ? sv[u] : samp;
+                hit_i = take ? (nb + u) : hit_i;
+                found = found || first_hit;
+                const bool brk = tracking && (since >= P.lmip_max_samples || inten < local_max * P.lmip_fall_off);  // :58
+                finished = finished || brk;
+            }
+        } else if (COUNT) {
+            steps += live ? (uint32_t)(tail ? (min(nb + U, nsteps) - nb) : U) : 0u;
+        }
+    };
+
     // span state: iterations [.., E) use LOD `code` (NL = none) with address constant Kc
     int code = NL, E = 0;
     uint32_t Kc = 0xFFFFFFFFu;
 
-    for (int n = 0;; n += U) {                       // n is wave-uniform: every ray starts at iteration 0
+    // Wave-static routing of fast runs (u8 rings): LDS bricks pay when the samples a wave fetches
+    // together fall into many different memory rows, i.e. when the march advances mostly along x
+    // (equal-iteration surfaces are then roughly perpendicular to x).  P.brick: 0 never, 1 auto, 2 always.
+    bool use_brick = false;
+    if (ESH == 0 && P.brick) {
+        const float vx = fabsf(R.step.x * P.size[0]), vy = fabsf(R.step.y * P.size[1]), vz = fabsf(R.step.z * P.size[2]);
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(frag);
+        const unsigned long long xm = __builtin_amdgcn_ballot_w64(frag && vx >= fmaxf(vy, vz));
+        use_brick = P.brick >= 2 || 2 * __builtin_popcountll(xm) > __builtin_popcountll(fm);
+    }
+    const int wave_lds = wave * kBrickBytes;
+
+    int n = 0;                                       // wave-uniform: every ray starts at iteration 0
+    while (true) {
         const bool alive = !finished && n < nsteps;
-        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // (alive_mask below is therefore non-zero)
+        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+        if (alive_mask == 0) break;
 
         // ---- span refresh for the lanes whose span has ended
         if (__builtin_amdgcn_ballot_w64(alive && n >= E) != 0) {
@@ -400,7 +517,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const uint32_t kx = (uint32_t)L.addw[0] - (px ? L.ring[0] : 0u);
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
-                        Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << 2) + L.base_bytes;   // mod 2^32
+                        Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << ESH) + L.base_bytes;  // mod 2^32
                         if (ev[l].cx > n) E = min(E, ev[l].cx);
                         if (ev[l].cy > n) E = min(E, ev[l].cy);
                         if (ev[l].cz > n) E = min(E, ev[l].cz);
@@ -412,45 +529,18 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             }
         }
 
-        float s[U];
-        // ---- fast batch: every live lane is inside one span of the same LOD for all U samples
-        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+        // ---- how many whole batches can every live lane run on one LOD with constant addressing?
         const int first = __builtin_amdgcn_readlane(code, (int)__builtin_ctzll(alive_mask));
-        const bool lane_ok = !alive || (code == first && n + U <= E);
-        const bool fast = __builtin_amdgcn_ballot_w64(!lane_ok) == 0;
-        const float basef = (float)n;
-        if (fast) {
-            if (first == NL) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) s[u] = 0.0f;          // no LOD holds these voxels (sample_vol.wgsl:62)
-            }
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                if (first == l) {
-                    const LodParams& L = P.lod[l];
-                    uint32_t off[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const float iter = basef + (float)u;
-                        const float dx = ((R.start.x + iter * R.step.x) * P.size[0]) * L.scale[0];
-                        const float dy = ((R.start.y + iter * R.step.y) * P.size[1]) * L.scale[1];
-                        const float dz = ((R.start.z + iter * R.step.z) * P.size[2]) * L.scale[2];
-                        const uint32_t row = __umul24((uint32_t)(int)dz, L.ring[1]) + (uint32_t)(int)dy;
-                        off[u] = __umul24(row, L.rx4) + Kc + ((uint32_t)(int)dx << 2);
-                    }
-                    if (alive) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[u], 0, 0));
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) s[u] = 0.0f;
-                    }
-                }
-            }
-        } else {
+        int lane_run = (code == first) ? (E - n) / U : 0;          // E <= nsteps: all those samples exist
+        if (first < NL && !P.lod_pow2[first < NL ? first : 0]) lane_run = alive ? 0 : lane_run;   // fused constant needs 2^-k scales
+        if (!alive) lane_run = 0x3fffffff;
+        int run = wave_reduce<false>(lane_run);
+
+        if (run <= 0) {
             // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
+            float s[U];
             uint32_t off[U];
+            const float basef = (float)n;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 off[u] = 0xFFFFFFFFu;
@@ -463,43 +553,146 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 for (int l = 0; l < NL; ++l) {
                     const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
                     if (__builtin_amdgcn_ballot_w64(sel) != 0) {
-                        const uint32_t ofs = lod_offset_wrapped(P.lod[l], dx, dy, dz);
+                        const uint32_t ofs = lod_offset_wrapped<ESH>(P.lod[l], dx, dy, dz);
                         off[u] = sel ? ofs : off[u];
                     }
                     done = done || sel;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                s[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[u], 0, 0));
+            for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
+            lmip_batch(s, n, alive, true);
+            n += U;
+            continue;
         }
 
-        // ---- LMIP state machine (raycast.wgsl:35-61); skipped while nothing can change
-        const bool tail = n + U > nsteps;                       // some samples of this lane do not exist
-        float m = -1.0f;
+        if (first == NL) {
+            // no LOD holds these voxels: every sample is 0 (sample_vol.wgsl:62)
+            float s[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) m = fmaxf(m, (tail && (n + u) >= nsteps) ? -1.0f : fabsf(s[u]));
-        const bool need = alive && (found || m >= P.lmip_threshold);
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool act = alive && (n + u) < nsteps && !finished;
-                const float inten = fabsf(s[u]);
-                if (COUNT) steps += act ? 1u : 0u;
-                const bool was_found = found;
-                const bool first_hit = act && !was_found && inten >= P.lmip_threshold;     // :37
-                const bool tracking = act && was_found;
-                since += tracking ? 1 : 0;                                                 // :47
-                const bool take = first_hit || (tracking && inten > local_max);            // :50
-                local_max = take ? inten : local_max;
-                samp = take ? s[u] : samp;
-                hit_i = take ? (n + u) : hit_i;
-                found = found || first_hit;
-                const bool brk = tracking && (since >= P.lmip_max_samples || inten < local_max * P.lmip_fall_off);  // :58
-                finished = finished || brk;
+            for (int u = 0; u < U; ++u) s[u] = 0.0f;
+            for (; run > 0; --run) {
+                lmip_batch(s, n, alive && !finished, false);
+                n += U;
+                if (__builtin_amdgcn_ballot_w64(alive && !finished) == 0) break;
             }
-        } else if (COUNT) {
-            steps += alive ? (uint32_t)(min(n + U, nsteps) - n) : 0u;
+            continue;
+        }
+
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (first != l) continue;
+            const LodParams& L = P.lod[l];
+            // scale is 2^-k here, so (coord*size)*scale == coord*(size*scale) bit for bit (scaling by a
+            // power of two commutes with rounding): one multiply per axis instead of two
+            const float ssx = P.size[0] * L.scale[0], ssy = P.size[1] * L.scale[1], ssz = P.size[2] * L.scale[2];
+
+            // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a
+            // slab (ic is monotone per axis: first and last sample bound the rest) is staged into LDS
+            // with coalesced 16-byte loads; the slab is then gathered from LDS, not through the L1,
+            // which serves gathers one lane-quad at a time.
+            if (ESH == 0) {
+                // slab length: about 12 ring voxels of travel (coarser LODs advance less per iteration)
+                const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
+                const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
+                while (use_brick && run >= slab / U && (L.ring[0] & 15u) == 0u) {
+                    const bool live = alive && !finished;
+                    const float fa = (float)n, fb = (float)(n + slab - 1);
+                    const int ax_ = (int)((R.start.x + fa * R.step.x) * ssx);
+                    const int ay_ = (int)((R.start.y + fa * R.step.y) * ssy);
+                    const int az_ = (int)((R.start.z + fa * R.step.z) * ssz);
+                    const int bx_ = (int)((R.start.x + fb * R.step.x) * ssx);
+                    const int by_ = (int)((R.start.y + fb * R.step.y) * ssy);
+                    const int bz_ = (int)((R.start.z + fb * R.step.z) * ssz);
+                    // exact box: (min, -max) per axis packed as two i16 -> three reductions (coords < 2^15)
+                    const short big = 0x7fff;
+                    short2_t px, py, pz;
+                    px.x = live ? (short)min(ax_, bx_) : big; px.y = live ? (short)(-max(ax_, bx_)) : big;
+                    py.x = live ? (short)min(ay_, by_) : big; py.y = live ? (short)(-max(ay_, by_)) : big;
+                    pz.x = live ? (short)min(az_, bz_) : big; pz.y = live ? (short)(-max(az_, bz_)) : big;
+                    px = wave_min2(px); py = wave_min2(py); pz = wave_min2(pz);
+                    if (px.x == big) { run = 0; break; }                 // no live lane left
+                    const int lx = px.x, hx = -(int)px.y, ly = py.x, hy = -(int)py.y, lz = pz.x, hz = -(int)pz.y;
+                    // 16-voxel groups aligned in RING space, so a group never straddles the wrap
+                    const int gx0 = lx - ((lx + L.addw[0]) & 15);
+                    const int ngx = ((hx - gx0) >> 4) + 1;
+                    const int lgx = ngx <= 1 ? 0 : (32 - __builtin_clz(ngx - 1));
+                    const int ny = hy - ly + 1, nz = hz - lz + 1;
+                    const int groups = (ny * nz) << lgx;
+                    if (ny >= 512 || groups * 16 > kBrickBytes) { use_brick = false; break; }   // does not fit: direct
+                    // rows advance by `rs` per 1-KiB load; (yy, zz) and the ring row track that incrementally
+                    const int rs = 64 >> lgx;
+                    const int qz = rs / ny, ry = rs - qz * ny;          // uniform
+                    const int row0 = lane >> lgx;
+                    int zz = (int)((float)row0 * (1.0f / (float)ny));    // row0 < 64: exact after the two fix-ups
+                    zz -= (zz * ny > row0) ? 1 : 0;
+                    zz += ((zz + 1) * ny <= row0) ? 1 : 0;
+                    int yy = row0 - zz * ny;
+                    uint32_t wx = (uint32_t)(gx0 + ((lane & ((1 << lgx) - 1)) << 4) + L.addw[0]);
+                    wx = min(wx, wx - L.ring[0]);
+                    const uint32_t src_x = L.base_bytes + wx;
+                    for (int g0 = 0; g0 < groups; g0 += 64) {
+                        uint32_t wy = (uint32_t)(ly + yy + L.addw[1]);
+                        uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);
+                        wy = min(wy, wy - L.ring[1]);
+                        wz = min(wz, wz - L.ring[2]);
+                        uint32_t src = mad24(mad24(wz, L.ring[1], wy), L.rx4, src_x);
+                        if (g0 + lane >= groups) src = 0xFFFFFFF0u;        // range-checked: loads zeros
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsrc, (__attribute__((address_space(3))) void*)(lds_all + wave_lds + g0 * 16),
+                            16, (int)src, 0, 0, 0);
+                        yy += ry; zz += qz;
+                        if (yy >= ny) { yy -= ny; zz += 1; }
+                    }
+                    // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
+                    const uint32_t sh = (uint32_t)lgx + 4u;
+                    const uint32_t bk = (uint32_t)wave_lds - (uint32_t)((((lz * ny + ly) << sh) + gx0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int k = 0; k < slab / U; ++k) {
+                        float s[U];
+                        const float basef = (float)n;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const float iter = basef + (float)u;
+                            const uint32_t ix = (uint32_t)(int)((R.start.x + iter * R.step.x) * ssx);
+                            const uint32_t iy = (uint32_t)(int)((R.start.y + iter * R.step.y) * ssy);
+                            const uint32_t iz = (uint32_t)(int)((R.start.z + iter * R.step.z) * ssz);
+                            const uint32_t a = shl_add(mad24(iz, (uint32_t)ny, iy), sh, ix + bk);
+                            s[u] = (float)lds_all[a & (4 * kBrickBytes - 1)];
+                        }
+                        lmip_batch(s, n, alive && !finished, false);
+                        n += U;
+                    }
+                    run -= slab / U;
+                    asm volatile("" ::: "memory");      // the next slab's loads must not overtake these LDS reads
+                }
+            }
+
+            // ---- direct fast batches: texel offset = ((iz*Ry + iy)*Rx + ix)*es + Kc, U loads in flight
+            for (; run > 0; --run) {
+                const bool live = alive && !finished;
+                if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+                float s[U];
+                uint32_t off[U];
+                const float basef = (float)n;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float iter = basef + (float)u;
+                    const uint32_t ix = (uint32_t)(int)((R.start.x + iter * R.step.x) * ssx);
+                    const uint32_t iy = (uint32_t)(int)((R.start.y + iter * R.step.y) * ssy);
+                    const uint32_t iz = (uint32_t)(int)((R.start.z + iter * R.step.z) * ssz);
+                    off[u] = mad24(mad24(iz, L.ring[1], iy), L.rx4, shl_add_c<ESH>(ix, Kc));
+                }
+                if (live) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) s[u] = 0.0f;
+                }
+                lmip_batch(s, n, live, false);
+                n += U;
+            }
         }
     }
 
@@ -530,9 +723,12 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    } else if (p.density_u8) {
+        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
-        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true>), dim3(nblocks), dim3(256), 0, stream, p);
-        else         hipLaunchKernelGGL((march_span<NL, 8, false>), dim3(nblocks), dim3(256), 0, stream, p);
+        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 2>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_span<NL, 8, false, 2>), dim3(nblocks), dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
         if (a.src_density) {
             const char* p = static_cast<const char*>(a.src_density) +
                             (int64_t)x * a.dstride[0] + (int64_t)y * a.dstride[1] + (int64_t)z * a.dstride[2];
-            a.ring_density[dst] = load_as_f32(p, a.density_dtype);
+            if (a.ring_density_u8) static_cast<uint8_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint8_t*>(p);
+            else static_cast<float*>(a.ring_density)[dst] = load_as_f32(p, a.density_dtype);
         }
         if (a.src_labels) {
             const char* p = static_cast<const char*>(a.src_labels) +
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
 }
 
 struct GatherArgs {
-    const float* ring_density; const uint32_t* ring_labels;
+    const void* ring_density; int32_t ring_density_u8; const uint32_t* ring_labels;
     int32_t ring[3], off[3], shape[3];
     float* out_density; uint32_t* out_labels;
 };
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
         const uint32_t z = (uint32_t)(q / (size_t)a.shape[1]);
         const size_t src = ((size_t)(z + a.off[2]) * (size_t)a.ring[1] + (size_t)(y + a.off[1])) *
                                (size_t)a.ring[0] + (size_t)(x + a.off[0]);
-        if (a.out_density) a.out_density[i] = a.ring_density[src];
+        if (a.out_density)
+            a.out_density[i] = a.ring_density_u8 ? (float)static_cast<const uint8_t*>(a.ring_density)[src]
+                                                 : static_cast<const float*>(a.ring_density)[src];
         if (a.out_labels)  a.out_labels[i]  = a.ring_labels[src];
     }
 }
@@ -130,11 +133,11 @@ hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t svr_launch_gather(const float* ring_density, const uint32_t* ring_labels, const int32_t ring[3],
+hipError_t svr_launch_gather(const void* ring_density, int ring_density_u8, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream) {
     GatherArgs a;
-    a.ring_density = ring_density; a.ring_labels = ring_labels;
+    a.ring_density = ring_density; a.ring_density_u8 = ring_density_u8; a.ring_labels = ring_labels;
     for (int i = 0; i < 3; ++i) { a.ring[i] = ring[i]; a.off[i] = off[i]; a.shape[i] = shape[i]; }
     a.out_density = out_density; a.out_labels = out_labels;
     const size_t n = (size_t)shape[0] * (size_t)shape[1] * (size_t)shape[2];

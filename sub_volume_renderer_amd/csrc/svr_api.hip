@@ -51,10 +51,15 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     int ndev = 0;
     SVR_HIP_TRY(hipGetDeviceCount(&ndev));
     SVR_REQUIRE(device >= 0 && device < ndev, "svr_create: no such HIP device (is a GPU visible?)");
-    for (int l = 0; l < num_lods; ++l)
+    for (int l = 0; l < num_lods; ++l) {
         for (int a = 0; a < 3; ++a)
             SVR_REQUIRE(lods[l].ring_dims[a] >= 1 && lods[l].ring_dims[a] < (1 << 24),
                         "svr_create: ring extent must be in [1, 2^24)");
+        SVR_REQUIRE(lods[l].density_storage == SVR_F32 || lods[l].density_storage == SVR_U8,
+                    "svr_create: density_storage must be SVR_F32 or SVR_U8");
+        SVR_REQUIRE(lods[l].density_storage == lods[0].density_storage,
+                    "svr_create: all LODs must use the same density_storage");
+    }
     DeviceGuard guard(device);
     svr_ctx* c = new svr_ctx();
     c->device = device; c->num_lods = num_lods;
@@ -65,6 +70,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
+    c->density_u8 = lods[0].density_storage == SVR_U8 ? 1 : 0;
 
     auto fail = [&](int code) { svr_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->render_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -75,31 +81,32 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         svr_set_error("svr_create: stream/event creation failed");
         return fail(SVR_ERR_HIP);
     }
-    size_t total = 0;
+    size_t total = 0;   // in VOXELS (256-voxel aligned): the same offsets serve the u8/f32 density and the u32 labels
     for (int l = 0; l < num_lods; ++l) {
         LodStorage& L = c->lod[l];
         for (int a = 0; a < 3; ++a) L.ring[a] = lods[l].ring_dims[a];
         L.voxels = (size_t)L.ring[0] * (size_t)L.ring[1] * (size_t)L.ring[2];
         memset(&L.state, 0, sizeof(L.state));
         L.state.scale[0] = L.state.scale[1] = L.state.scale[2] = 1.0f;
-        c->lod_base_bytes[l] = total;
-        total += (L.voxels * sizeof(float) + 255) & ~(size_t)255;
+        c->lod_base_bytes[l] = total;                         // voxel offset of this LOD
+        total += (L.voxels + 255) & ~(size_t)255;
     }
-    c->density_all_bytes = total;
+    const size_t des = c->density_u8 ? 1 : sizeof(float);
+    c->density_all_bytes = total * des + 64;                 // + slack: 16-byte brick loads may overrun a row end
     // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
-    if (hipMalloc((void**)&c->density_all, total) != hipSuccess ||
-        hipMalloc((void**)&c->labels_all, total) != hipSuccess) {
+    if (hipMalloc((void**)&c->density_all, c->density_all_bytes) != hipSuccess ||
+        hipMalloc((void**)&c->labels_all, total * sizeof(uint32_t)) != hipSuccess) {
         svr_set_error("svr_create: out of device memory for ring textures");
         return fail(SVR_ERR_NOMEM);
     }
-    if (hipMemsetAsync(c->density_all, 0, total, c->upload_stream) != hipSuccess ||
-        hipMemsetAsync(c->labels_all, 0, total, c->upload_stream) != hipSuccess) {
+    if (hipMemsetAsync(c->density_all, 0, c->density_all_bytes, c->upload_stream) != hipSuccess ||
+        hipMemsetAsync(c->labels_all, 0, total * sizeof(uint32_t), c->upload_stream) != hipSuccess) {
         svr_set_error("svr_create: memset failed");
         return fail(SVR_ERR_HIP);
     }
     for (int l = 0; l < num_lods; ++l) {
-        c->lod[l].density = reinterpret_cast<float*>(reinterpret_cast<char*>(c->density_all) + c->lod_base_bytes[l]);
-        c->lod[l].labels = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->labels_all) + c->lod_base_bytes[l]);
+        c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
+        c->lod[l].labels = c->labels_all + c->lod_base_bytes[l];
     }
     if (hipEventRecord(c->uploads_published, c->upload_stream) != hipSuccess) return fail(SVR_ERR_HIP);
     c->have_published = true;
@@ -244,6 +251,8 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     SVR_REQUIRE(!density || (des && density_strides), "svr_upload_region: bad density dtype/strides");
     SVR_REQUIRE(!labels || (les && labels_strides), "svr_upload_region: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
+    SVR_REQUIRE(!density || !c->density_u8 || density_dtype == SVR_U8,
+                "svr_upload_region: a context with SVR_U8 density storage only accepts uint8 density sources");
     if (shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return SVR_OK;
     DeviceGuard guard(c->device);
     rc = ensure_staging(c);
@@ -272,7 +281,7 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
         a.dstride[0] = (int64_t)des; a.dstride[1] = (int64_t)des * shape[0]; a.dstride[2] = (int64_t)des * shape[0] * shape[1];
         a.src_labels = labels ? static_cast<char*>(S.dev) + lofs : nullptr; a.labels_dtype = labels_dtype;
         a.lstride[0] = (int64_t)les; a.lstride[1] = (int64_t)les * shape[0]; a.lstride[2] = (int64_t)les * shape[0] * shape[1];
-        a.ring_density = L.density; a.ring_labels = L.labels;
+        a.ring_density = L.density; a.ring_labels = L.labels; a.ring_density_u8 = c->density_u8;
         for (int i = 0; i < 3; ++i) { a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i]; }
         a.dst_off[2] = dst_off[2] + z0; a.shape[2] = z1 - z0;
         SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
@@ -290,11 +299,14 @@ int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], cons
     SVR_REQUIRE(!density || (svr_dtype_size(density_dtype) && density_strides), "svr_upload_region_device: bad density dtype/strides");
     SVR_REQUIRE(!labels || (svr_dtype_size(labels_dtype) && labels_strides), "svr_upload_region_device: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
+    SVR_REQUIRE(!density || !c->density_u8 || density_dtype == SVR_U8,
+                "svr_upload_region_device: a context with SVR_U8 density storage only accepts uint8 density sources");
     DeviceGuard guard(c->device);
     rc = uploads_after_render(c);
     if (rc) return rc;
     LodStorage& L = c->lod[lod];
     ScatterArgs a;
+    a.ring_density_u8 = c->density_u8;
     a.src_density = density; a.density_dtype = density_dtype;
     a.src_labels = labels; a.labels_dtype = labels_dtype;
     for (int i = 0; i < 3; ++i) {
@@ -322,7 +334,7 @@ int svr_clear_lod(svr_ctx* c, int lod) {
     int rc = uploads_after_render(c);
     if (rc) return rc;
     LodStorage& L = c->lod[lod];
-    SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * sizeof(float), c->upload_stream));
+    SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * (c->density_u8 ? 1 : sizeof(float)), c->upload_stream));
     SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
     return SVR_OK;
 }
@@ -342,7 +354,7 @@ int svr_read_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t sha
         if (dtmp) (void)hipFree(dtmp);
         svr_set_error("svr_read_region: out of device memory"); return SVR_ERR_NOMEM;
     }
-    hipError_t e = svr_launch_gather(L.density, L.labels, L.ring, off, shape, dtmp, ltmp, c->upload_stream);
+    hipError_t e = svr_launch_gather(L.density, c->density_u8, L.labels, L.ring, off, shape, dtmp, ltmp, c->upload_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->upload_stream);
     if (e == hipSuccess && dtmp) e = hipMemcpy(density_out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess && ltmp) e = hipMemcpy(labels_out, ltmp, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -383,19 +395,12 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.num_lods = c->num_lods;
     P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
     // variant: bits 0-3 kernel kind (0 batched U=8, 1 simple, 2 batched U=4), bits 4-7 = 1 + log2 of the
-    // wave tile width (0 = default 8x8), bit 8 = disable the iteration skew
+    // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
     int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;
     if (lw > 6) lw = 6;
     if ((c->variant & 15) == 1) lw = 3;                       // the simple kernel is 8x8 only
     P.tile_log2w = lw;
-    P.skew = (c->variant & 256) ? 0 : 1;
-    P.shear = (c->variant & 512) ? 0 : 1;
-    {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
-        const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
-        float wx[4];
-        mat_vec4(cam->world, ex, wx);
-        mat_vec4(P.pc, wx, P.xdir);
-    }
+    P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     const int bw = 2 << lw, bh = 2 * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     for (int l = 0; l < c->num_lods; ++l) {
@@ -410,11 +415,25 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             Q.scale[a] = L.state.scale[a];
             Q.addw[a] = (int32_t)Q.wrap0[a] - Q.off[a];
         }
-        Q.rx4 = Q.ring[0] * 4u;
-        Q.base_bytes = (uint32_t)c->lod_base_bytes[l];
+        {
+            bool ok = true;
+            for (int a = 0; a < 3; ++a) {
+                int e = 0;
+                const float m = frexpf(Q.scale[a], &e);
+                ok = ok && m == 0.5f && Q.scale[a] > 0.0f && Q.scale[a] <= 1.0f;    // exactly 2^-k
+                ok = ok && P.size[a] * Q.scale[a] < 8388608.0f;                      // indices < 2^23
+                ok = ok && Q.ring[a] < (1u << 15);                                   // packed i16 brick boxes
+            }
+            ok = ok && (double)P.size[1] * Q.scale[1] * Q.ring[1] < 16777216.0;      // row index < 2^24
+            P.lod_pow2[l] = ok ? 1 : 0;
+        }
+        const uint32_t des = c->density_u8 ? 1u : 4u;
+        Q.rx4 = Q.ring[0] * des;
+        Q.base_bytes = (uint32_t)(c->lod_base_bytes[l] * des);
     }
     P.density_all = c->density_all;
     P.density_all_bytes = c->density_all_bytes < ((size_t)1 << 32) ? (uint32_t)c->density_all_bytes : 0u;
+    P.density_u8 = c->density_u8;
     return SVR_OK;
 }
 

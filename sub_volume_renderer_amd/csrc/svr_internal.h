@@ -17,7 +17,7 @@
 // buffers each step: raycast.wgsl:16-20, sample_vol.wgsl:7,14-15).
 // ---------------------------------------------------------------------------
 struct LodParams {
-    const float*    density;   // ring texture r32float, [z][y][x]
+    const void*     density;   // ring texture r32float (or u8 storage), [z][y][x]
     const uint32_t* labels;    // ring texture r32uint
     int32_t  off[3];           // current_logical_offset_in_pixels (x,y,z)
     uint32_t shape[3];         // current_logical_shape_in_pixels
@@ -26,7 +26,7 @@ struct LodParams {
     float    scale[3];         // scale_factor
     uint32_t base_bytes;       // byte offset of this LOD's density ring inside MarchParams::density_all
     int32_t  addw[3];          // wrap0 - off: ring slot = wrap(ic + addw)
-    uint32_t rx4;              // ring[0] * 4 (row pitch in bytes)
+    uint32_t rx4;              // row pitch of the density ring in bytes (ring[0] * element size)
 };
 
 struct MarchParams {
@@ -54,21 +54,22 @@ struct MarchParams {
     uint32_t* steps;
     // all LOD density rings live in ONE allocation so a single buffer resource
     // (32-bit byte offsets, hardware range check) addresses every LOD
-    const float* density_all;
+    const void* density_all;
     uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
+    int32_t  density_u8;           // 1: density rings hold bytes (svr_lod_desc::density_storage)
     // block -> tile mapping
     int32_t tiles_x, tiles_y;
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
-    int32_t skew;                  // 1: per-lane iteration skew (see march_kernel.hip)
-    int32_t shear;                 // 1: lanes follow the screen direction of the volume's x axis
-    float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)
+    int32_t brick;                 // 0 never / 1 per-wave heuristic / 2 always: LDS bricks (u8 rings only)
+    int32_t lod_pow2[SVR_MAX_LODS];// 1: all three scale factors of the LOD are powers of two and the
+                                   //    voxel indices fit the 24-bit multiplier (fast path eligible)
     LodParams lod[SVR_MAX_LODS];
 };
 
 struct LodStorage {
     int32_t  ring[3];          // x,y,z
     size_t   voxels;
-    float*    density;
+    void*     density;
     uint32_t* labels;
     svr_lod_state state;
 };
@@ -84,7 +85,8 @@ struct svr_ctx {
     int device;
     int num_lods;
     LodStorage lod[SVR_MAX_LODS];
-    float*    density_all;           // one allocation, LOD rings at 256-byte aligned offsets
+    void*     density_all;           // one allocation, LOD rings at 256-byte aligned offsets
+    int       density_u8;            // ring element type: 0 f32, 1 u8
     uint32_t* labels_all;
     size_t    density_all_bytes;
     size_t    lod_base_bytes[SVR_MAX_LODS];
@@ -126,13 +128,14 @@ hipError_t svr_launch_march(const MarchParams& p, int variant, hipStream_t strea
 struct ScatterArgs {
     const void* src_density; int density_dtype; int64_t dstride[3];   // bytes per x,y,z step
     const void* src_labels;  int labels_dtype;  int64_t lstride[3];
-    float* ring_density; uint32_t* ring_labels;
+    void* ring_density; uint32_t* ring_labels;
+    int32_t ring_density_u8;
     int32_t ring[3];
     int32_t dst_off[3];
     int32_t shape[3];
 };
 hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
-hipError_t svr_launch_gather(const float* ring_density, const uint32_t* ring_labels, const int32_t ring[3],
+hipError_t svr_launch_gather(const void* ring_density, int ring_density_u8, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream);
 hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,

@@ -34,6 +34,7 @@ class SceneSpec:
     centers: list = field(default_factory=list)   # [(position_xyz, sizes | None)]
     region: FrameRegion | None = None
     colorspace: str = "srgb"
+    ring_storage: str = "native"
 
     def camera(self) -> PerspectiveCamera:
         cam = PerspectiveCamera(self.fov, self.width / self.height, depth_range=self.depth_range)
@@ -75,6 +76,7 @@ def build(spec: SceneSpec, device: int | None = None) -> BuiltScene:
         buffer_shape_in_chunks=list(spec.ring_shapes),
         chunk_shape_in_pixels=list(spec.chunk_shapes),
         device=device,
+        ring_storage=spec.ring_storage,
     )
     vol.world.position = spec.world_position
     vol.world.scale = spec.world_scale

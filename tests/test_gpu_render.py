@@ -37,13 +37,41 @@ def test_config1_multi_scale_demo():
     assert set(np.unique(ref.label[ref.flags == 2])) == {0, 1, 2}      # every LOD contributes hits
 
 
+@pytest.mark.parametrize("storage", ["native", "float32"], ids=["u8rings", "f32rings"])
 @pytest.mark.parametrize("inside", [False, True], ids=["K1_outside", "K2_inside"])
 @pytest.mark.parametrize("full", [False, True], ids=["lmip", "full"])
-def test_synthetic_three_lods(inside, full):
-    scene = testing.build(testing.synthetic_spec(64, 160, 96, inside=inside, full=full))
+def test_synthetic_three_lods(inside, full, storage):
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside, full=full)
+    spec.ring_storage = storage
+    scene = testing.build(spec)
+    assert scene.volume._rings.density_storage == ("uint8" if storage == "native" else "float32")
     _, ref, rep = check(scene, want_hits=not full)
     if full:
         assert rep["n_hit"] == 0 and rep["n_miss"] > 0                 # threshold = +inf: every ray runs all nsteps
+
+
+@pytest.mark.parametrize("variant", [0x000, 0x200, 0x100, 0x001, 0x250, 0x230],
+                         ids=["auto", "brick", "nobrick", "simple", "brick16x4", "brick4x16"])
+@pytest.mark.parametrize("cam", ["K1", "K2", "-x", "-y", "-z"])
+def test_kernel_variants_bit_identical(variant, cam):
+    """Every kernel variant (LDS bricks on/off, span vs simple march, tile shapes) must agree with the
+    oracle bit for bit, for views entering through each face (rings 16-aligned so bricks are used)."""
+    import ctypes as C
+
+    from sub_volume_renderer_amd import _native as N
+
+    spec = testing.synthetic_spec(128, 192, 128, inside=(cam == "K2"), threshold=0.45,
+                                  chunk_shapes=[(8, 8, 16), (4, 4, 16), (2, 2, 16)],
+                                  ring_shapes=[(6, 6, 3), (12, 12, 3), (16, 16, 2)])
+    if cam.startswith("-"):
+        d = {"-x": (-1, 0.05, 0.08), "-y": (0.06, -1, 0.04), "-z": (0.03, 0.07, -1)}[cam]
+        d = np.array(d) / np.linalg.norm(d)
+        c = 63.5
+        spec.cam_position = tuple(np.array([c, c, c]) + 1.6 * 128 * d)
+        spec.cam_target = (c, c, c)
+    scene = testing.build(spec)
+    N.check(N.lib().svr_set_variant(scene.volume.prepare(), variant), "svr_set_variant")
+    check(scene)
 
 
 def test_synthetic_128_srgb_off_and_many_colors():
