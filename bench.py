@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--band-h", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-stride", type=int, default=0, help="oracle sample: every k-th row (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
+                    help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
+    ap.add_argument("--modes", default="full,lmip", help="march modes to time (full must be included)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled rows with the oracle")
     return ap.parse_args()
 
@@ -93,6 +96,7 @@ def main():
         dist.barrier()
 
     from sub_volume_renderer_amd import FrameRegion, Roi, _native as N, synth, testing
+    from sub_volume_renderer_amd.distributed import TiledFrame
 
     dev = torch.device("cuda", local_rank)
     n, W, H = args.n, args.width, args.height
@@ -101,6 +105,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     spec = config2_spec(n, W, H, args.camera, pairs)
+    spec.ring_storage = args.ring_storage
     t0 = time.time()
     scene = testing.build(spec, device=local_rank)
     scene.volume.synchronize()
@@ -108,15 +113,18 @@ def main():
     vol, cam = scene.volume, scene.camera
     N.check(N.lib().svr_set_variant(vol._rings.handle, args.variant), "svr_set_variant")
 
-    region = FrameRegion.full(W, H) if world == 1 else FrameRegion.stripes(W, H, rank, world, args.band_h)
+    tiled = TiledFrame(W, H, rank, world, args.band_h)
+    region = tiled.region
     full_frame = FrameRegion.full(W, H)
+    modes = [m for m in args.modes.split(",") if m]
+    assert "full" in modes, "--modes must include full (the headline number)"
 
     def set_mode(full):
         vol.material.lmip_threshold = float("inf") if full else 0.5 * 255.0
 
     # ---- exact step / hit / pixel counts of the whole frame (instrumented kernel, untimed)
     counts = {}
-    for mode in ("full", "lmip"):
+    for mode in modes:
         set_mode(mode == "full")
         r = vol.render(cam, W, H, region=full_frame, count_steps=True)
         torch.cuda.synchronize()
@@ -127,20 +135,11 @@ def main():
 
     # ---- outputs for the timed loop
     out = vol._outputs(region.out_h, region.out_w, False)
-    gathered = frame_rgba = None
-    if world > 1 and rank == 0:
-        gathered = torch.empty((world, region.out_h, W, 4), dtype=torch.float32, device=dev)
-        frame_rgba = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
 
     def frame():
         res = vol.render(cam, W, H, region=region, out=out)
         if world > 1:
-            dist.gather(res.rgba, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                N.check(N.lib().svr_untile_stripes(vol._rings.handle, C.c_void_p(gathered.data_ptr()),
-                                                   C.c_void_p(frame_rgba.data_ptr()), W, H, args.band_h, world,
-                                                   region.out_h, 16, C.c_void_p(stream.cuda_stream)), "untile")
+            tiled.gather(res.rgba, dst=0, volume=vol)      # RCCL gather of the RGBA bands + un-tile kernel
 
     def timed(mode, steps, warmup):
         set_mode(mode == "full")
@@ -163,7 +162,7 @@ def main():
         return dt
 
     dt_full = timed("full", args.steps, args.warmup)
-    dt_lmip = timed("lmip", args.steps, args.warmup)
+    dt_lmip = timed("lmip", args.steps, args.warmup) if "lmip" in modes else None
 
     # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
     def kernel_ms(mode, iters=10):
@@ -180,21 +179,27 @@ def main():
 
     torch.cuda.synchronize()
     k_full = kernel_ms("full")
-    k_lmip = kernel_ms("lmip")
+    k_lmip = kernel_ms("lmip") if "lmip" in modes else None
 
     def algo_bytes(c, npix):
         # 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
         # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
         return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
 
+    u8 = vol._rings.density_storage == "uint8"
+
+    def native_bytes(c, npix):
+        # what the kernel actually has to fetch with byte rings: 1 B per ray-step
+        return (1 if u8 else 4) * c["steps"] + 4 * c["hits"] + 25 * npix
+
     result = None
     if world == 1:
         npix = W * H
         a_full = algo_bytes(counts["full"], npix) / (k_full * 1e-3) / 1e9
-        a_lmip = algo_bytes(counts["lmip"], npix) / (k_lmip * 1e-3) / 1e9
+        a_lmip = algo_bytes(counts["lmip"], npix) / (k_lmip * 1e-3) / 1e9 if k_lmip else None
     if rank == 0:
         ms_full = dt_full / args.steps * 1e3
-        ms_lmip = dt_lmip / args.steps * 1e3
+        ms_lmip = dt_lmip / args.steps * 1e3 if dt_lmip else None
         result = {
             "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
             "value": counts["full"]["steps"] / (dt_full / args.steps) / 1e6,
@@ -214,23 +219,30 @@ def main():
                 "rays_with_fragment": counts["full"]["frags"],
                 "parallelism": "single" if world == 1 else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
                 "kernel_variant": args.variant,
+                "ring_storage": vol._rings.density_storage,
             },
-            "lmip": {
+        }
+        if dt_lmip:
+            result["lmip"] = {
                 "march_mode": "lmip threshold=0.5*255 fall_off=0.5 max_samples=10",
                 "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
                 "value": counts["lmip"]["steps"] / (dt_lmip / args.steps) / 1e6, "unit": "Mray-steps/s",
                 "frames_per_s": args.steps / dt_lmip, "ms_per_step": ms_lmip,
-            },
-            "setup_s": {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)},
-        }
+            }
+        result["setup_s"] = {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)}
         if world == 1:
             result["roofline"] = {
                 "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": a_full / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "march (full mode)", "kernel_ms": k_full,
+                "kernel": "march_span (full mode)", "kernel_ms": k_full,
                 "algorithmic_bytes": algo_bytes(counts["full"], W * H),
+                "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
+                "native_layout": {"bytes": native_bytes(counts["full"], W * H),
+                                  "achieved": native_bytes(counts["full"], W * H) / (k_full * 1e-3) / 1e9,
+                                  "note": "byte rings: 1 B/ray-step actually needed" if u8 else "same as reference layout"},
             }
-            result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": k_lmip}
+            if k_lmip:
+                result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": k_lmip}
 
     # ---- CPU baseline: the oracle (a port: the reference itself cannot run offline) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -244,27 +256,42 @@ def main():
                               offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
                               shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
                               scale=tuple(float(v) for v in u["scale_factor"])))
-        stride = args.cpu_row_stride or max(1, int(round(16 * (n / 1024.0) ** 1)))
-        nrows = -(-H // stride)
-        sample = FrameRegion(0, 0, W, nrows, 1, stride)
         mats = spec.matrices()
         vdim = tuple(float(v) for v in vol._volume_dimensions)
+        m_full = dict(spec.material)
+        m_full["lmip_threshold"] = float("inf")
+        # calibrate on every 32nd row, then size the sample to ~cpu_seconds of oracle time
+        cal = FrameRegion(0, 0, W, -(-H // 32), 1, 32)
+        t = time.perf_counter()
+        ref = oracle_lmip.render(rings, mats, vdim, m_full, W, H, region=cal, nthreads=0)
+        t_cal = time.perf_counter() - t
+        rate = max(1.0, ref.steps.astype(np.int64).sum() / t_cal)
+        frac = min(1.0, args.cpu_seconds * rate / max(1, counts["full"]["steps"]))
+        stride = max(1, int(round(1.0 / frac)))
+        nrows = -(-H // stride)
+        sample = FrameRegion(0, 0, W, nrows, 1, stride)
+        est = frac * counts["full"]["steps"] / rate                     # seconds for one pass over the sample
+        reps = max(1, min(16, int(round(args.cpu_seconds / max(est, 1e-3))))) if stride == 1 else 1
         base = {}
-        for mode in ("full", "lmip"):
+        for mode in modes:
             m = dict(spec.material)
             m["lmip_threshold"] = float("inf") if mode == "full" else 0.5 * 255.0
             t = time.perf_counter()
-            ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=0)
+            for _ in range(reps if mode == "full" else 1):
+                ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=0)
             dtc = time.perf_counter() - t
-            base[mode] = (int(ref.steps.astype(np.int64).sum()), dtc, ref)
+            k = reps if mode == "full" else 1
+            base[mode] = (k * int(ref.steps.astype(np.int64).sum()), dtc, ref)
         cores = oracle_lmip.lib().svr_oracle_max_threads()
         st, dtc, ref = base["full"]
         result["cpu_baseline"] = {
             "value": st / dtc / 1e6, "unit": "Mray-steps/s", "cores": cores, "kind": "port",
-            "sample": f"every {stride}th row of the same frame ({nrows} rows, {st} ray-steps, {dtc:.1f} s), "
-                      "full mode; CPU restatement of the reference shader (reference itself not runnable offline)",
-            "lmip_value": base["lmip"][0] / base["lmip"][1] / 1e6,
+            "sample": f"{reps} pass(es) over every {stride}th row of the same frame ({nrows} rows; {st} ray-steps, {dtc:.1f} s of oracle time), "
+                      "full mode, all host cores (OpenMP); CPU restatement of the reference shader "
+                      "(the reference itself cannot run offline: pygfx/wgpu absent)",
         }
+        if "lmip" in base:
+            result["cpu_baseline"]["lmip_value"] = base["lmip"][0] / base["lmip"][1] / 1e6
         if args.check:
             set_mode(True)
             res = vol.render(cam, W, H, region=sample, count_steps=True)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's roofline block (same command, full mode only so that every
+# march dispatch in the trace is the timed workload).  usage: tools/profile_bench.sh <tag>
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/profile_$TAG; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --modes full --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUFFER_WAVEFRONTS_sum" \
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
+            "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex march --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1
+done
+grep -h '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
+python3 $ROOT/tools/pmc_summary.py $OUT march_span > $OUT/summary.txt 2>&1
+f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); head -1 $f > $OUT/kernel_stats_march.csv; grep march_ $f >> $OUT/kernel_stats_march.csv
+cat $OUT/summary.txt
