@@ -1,0 +1,115 @@
+"""The shader oracle (oracle/lmip_oracle.c): committed golden vectors, agreement with the independent
+numpy restatement, and hand-derived known answers.  Render parity is *unpinned* by the reference (it
+holds no rendered fixture); these tests pin the restatement itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import lmip, lmip_numpy
+from sub_volume_renderer_amd import testing
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["demo", "k1", "k2"])
+def test_oracle_reproduces_committed_golden(name):
+    r = lmip.render_spec(make_golden.specs()[name], nthreads=2)
+    for plane in ("label", "flags", "steps"):
+        np.testing.assert_array_equal(getattr(r, plane), GOLD[f"{name}_{plane}"])
+    np.testing.assert_allclose(r.rgba, GOLD[f"{name}_rgba"], rtol=0, atol=1e-6)      # libm pow/exp may differ by an ulp
+    np.testing.assert_allclose(r.depth, GOLD[f"{name}_depth"], rtol=0, atol=1e-6)
+    assert (GOLD[f"{name}_flags"] == 2).sum() > 0
+
+
+@pytest.mark.parametrize("name", ["demo", "k1", "k2"])
+def test_two_independent_restatements_agree(name):
+    spec = make_golden.specs()[name]
+    a = lmip.render_spec(spec, nthreads=2)
+    b = lmip_numpy.render_spec(spec)
+    np.testing.assert_array_equal(a.flags, b["flags"])
+    np.testing.assert_array_equal(a.steps, b["steps"])
+    np.testing.assert_array_equal(a.label, b["label"])
+    np.testing.assert_allclose(a.rgba, b["rgba"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a.depth, b["depth"], rtol=0, atol=2e-6)
+
+
+def _uniform_scene(value, threshold):
+    data = np.full((16, 16, 16), value, np.float32)
+    seg = np.full((16, 16, 16), 2, np.uint32)
+    spec = testing.synthetic_spec(16, 40, 30, pairs=[(data, seg)], chunk_shapes=[(4, 4, 4)], ring_shapes=[(4, 4, 4)])
+    spec.material = dict(lmip_threshold=threshold, fog_density=0.25, fog_color=(0.2, 0.4, 0.6),
+                         colors=[(0.0, 1.0, 1.0), (0.5, 1.0, 1.0), (1.0 / 3.0, 1.0, 1.0)], opacity=0.9)
+    spec.centers = [((7.5, 7.5, 7.5), [(16, 16, 16)])]
+    return spec
+
+
+def test_all_zero_volume_is_black_and_opaque():
+    """The reference's (stale) render test idea: an all-zero volume renders black (tests/basic_volume/
+    test_volume_texture_update.py:17-38); fs_main.wgsl:93-98 gives (0,0,0,1), depth 0."""
+    r = lmip.render_spec(_uniform_scene(0.0, 0.5))
+    frag = r.flags != 0
+    assert frag.sum() > 0 and (r.flags == 2).sum() == 0
+    assert np.all(r.rgba[frag] == np.array([0, 0, 0, 1], np.float32))
+    assert np.all(r.rgba[~frag] == 0) and np.all(r.depth == 0)
+    assert np.all(r.steps[~frag] == 0) and np.all(r.steps[frag] >= 1)
+
+
+def test_uniform_one_volume_known_colour():
+    """Every ray hits at iteration 0 (value 1 >= 0.5); with lmip_max_samples = 10 and no fall-off it
+    stops after min(nsteps, 11) samples.  v = 1 -> srgb2physical(1) = 1; label 2 -> hue 1/3 -> pure
+    green; offset = 0 -> fog factor 1 -> rgba = (0, 1, 0, opacity)."""
+    r = lmip.render_spec(_uniform_scene(1.0, 0.5))
+    hit = r.flags == 2
+    # rays grazing the far faces sample exactly at coord == size (voxel index 16: outside every ROI, value 0)
+    assert hit.sum() > 0 and (r.flags == 1).sum() < 0.05 * hit.sum()
+    assert np.all(r.steps[r.flags == 1] <= 2)
+    want = np.tile(np.array([0, 1, 0, 0.9], np.float32), (hit.sum(), 1))
+    np.testing.assert_allclose(r.rgba[hit], want, atol=5e-3)          # grazing rays hit at iteration 1: a trace of fog
+    exact = np.all(np.abs(r.rgba[hit] - want) <= 1e-6, axis=1)
+    assert exact.mean() > 0.5         # rays entering through a low face: hit at iteration 0, offset 0, no fog at all
+    assert np.all(r.label[hit] == 2)
+    full = lmip.render_spec(_uniform_scene(1.0, float("inf")))        # threshold never reached
+    # raycast.wgsl:43,47,58: 1 + max_samples samples from the first hit; rays entering through a high face
+    # take their first sample at coord == size (outside every ROI), so they run one step more
+    extra = r.steps[hit].astype(int) - np.minimum(full.steps[hit], 11).astype(int)
+    assert set(np.unique(extra)) <= {0, 1}
+
+
+def test_lod_fallthrough_first_roi_wins_even_if_zero():
+    """sample_vol.wgsl:51-63: the first LOD whose ROI holds the voxel wins even when its value is 0."""
+    n = 16
+    d0 = np.zeros((n, n, n), np.float32)                 # LOD 0: all zero, loaded everywhere
+    d1 = np.ones((n // 2,) * 3, np.float32)              # LOD 1: all one
+    s0 = np.zeros(d0.shape, np.uint32)
+    s1 = np.ones(d1.shape, np.uint32)
+    spec = testing.synthetic_spec(n, 32, 24, pairs=[(d0, s0), (d1, s1)], chunk_shapes=[(4, 4, 4), (2, 2, 2)],
+                                  ring_shapes=[(4, 4, 4), (4, 4, 4)])
+    spec.material.update(lmip_threshold=0.5, clim=(0, 1))
+    spec.centers = [((7.5, 7.5, 7.5), [(16, 16, 16), (8, 8, 8)])]
+    r = lmip.render_spec(spec)
+    assert (r.flags == 2).sum() == 0                     # LOD 0 covers everything with zeros
+    spec.centers = [((7.5, 7.5, 7.5), [(8, 8, 8), (8, 8, 8)])]       # LOD 0 only in the middle
+    r = lmip.render_spec(spec)
+    assert (r.flags == 2).sum() > 0 and set(np.unique(r.label[r.flags == 2])) == {1}
+
+
+def test_region_rendering_matches_full_frame():
+    from sub_volume_renderer_amd import FrameRegion
+
+    spec = make_golden.specs()["k1"]
+    full = lmip.render_spec(spec)
+    tile = lmip.render_spec(spec, region=FrameRegion.tile(16, 8, 40, 24))
+    np.testing.assert_array_equal(tile.rgba, full.rgba[8:32, 16:56])
+    st = FrameRegion.stripes(80, 48, 1, 3, band_h=8)
+    r = lmip.render_spec(spec, region=st)
+    for row in range(st.out_h):
+        y = st.y0 + (row // 8) * st.band_pitch + row % 8
+        if y < 48:
+            np.testing.assert_array_equal(r.label[row], full.label[y])
+        else:
+            assert np.all(r.flags[row] == 0)
