@@ -169,6 +169,17 @@ int  svr_upload_region_device(svr_ctx* ctx, int lod,
  * next draw on the same queue (FUTURE.md:47-58). */
 int  svr_publish_uploads(svr_ctx* ctx);
 
+/* ---- asynchronous streaming (the reference has none: FUTURE.md:3-67 lists it as future work).
+ * Protocol, driven by the host (SubVolume.center_on_position(..., asynchronous=True)):
+ *   1. svr_set_lod_state(ROI := old ROI intersected with the new one)  -- renders enqueued from now on
+ *      never touch a ring slot that is about to be overwritten; coarser LODs cover the gap;
+ *   2. svr_upload_region(...) for the new chunks, from a worker thread: the copies are ordered
+ *      behind the last render that was enqueued with the old ROI, and run beside later renders;
+ *   3. svr_mark_uploads(); when svr_uploads_pending() reports 0, svr_set_lod_state(ROI := new).
+ * svr_render never waits for marked-but-unpublished uploads. */
+int  svr_mark_uploads(svr_ctx* ctx);
+int  svr_uploads_pending(svr_ctx* ctx, int* pending);
+
 /* ---- readback of a ring region into packed host arrays (shader-order
  * shape, x fastest): the texture.data numpy mirror the reference's tests read
  * (tests/wrapping_buffer/test_load_logical_roi.py:5-76).  Synchronous. */

@@ -110,6 +110,8 @@ SIGNATURES = {
     "svr_upload_region_device": (C.c_int, [C.c_void_p, C.c_int, _I3, _I3,
                                            C.c_void_p, C.c_int, _L3, C.c_void_p, C.c_int, _L3]),
     "svr_publish_uploads": (C.c_int, [C.c_void_p]),
+    "svr_mark_uploads": (C.c_int, [C.c_void_p]),
+    "svr_uploads_pending": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "svr_read_region": (C.c_int, [C.c_void_p, C.c_int, _I3, _I3, C.c_void_p, C.c_void_p]),
     "svr_clear_lod": (C.c_int, [C.c_void_p, C.c_int]),
     "svr_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),

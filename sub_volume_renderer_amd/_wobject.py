@@ -139,6 +139,11 @@ class SubVolume(_HasWorld):
         self.volume_dimensions = base_data.shape
         self._material_version_pushed = -1
         self._out_cache = {}
+        self._worker = None
+        self._worker_error = None
+        self._inflight = []
+        self._submitted = 0
+        self._completed = 0
 
     # -- _wobject.py:103-133 ---------------------------------------------------
     @property
@@ -162,8 +167,13 @@ class SubVolume(_HasWorld):
         return [b.segmentations_texture for b in self.wrapping_buffers]
 
     # -- _wobject.py:135-208 ---------------------------------------------------
-    def center_on_position(self, position, sizes=None):
+    def center_on_position(self, position, sizes=None, *, asynchronous: bool = False):
         """Center every LOD's ring window on a world position (x, y, z).
+
+        ``asynchronous=True`` (not in the reference, whose uploads block the render thread —
+        FUTURE.md:3-7): the call only plans the loads and publishes the shrunk ROIs; the chunk copies
+        run on a worker thread / the upload stream beside later renders, and :meth:`render` publishes
+        the full new ROIs once they have landed (:meth:`poll_uploads`).
 
         ``sizes``: window size per scale in that scale's voxels (numpy order).  By
         default one chunk less than the ring per axis, so that growing the window
@@ -180,11 +190,69 @@ class SubVolume(_HasWorld):
             )
         # world -> data space; the matrix works in shader order, so reverse to numpy order
         p = (self.world.inverse_matrix @ np.array([*position, 1.0]))[:3][::-1]
+        jobs = []
         for size, buffer in zip(sizes, self.wrapping_buffers):
             offset = tuple(int(c * f - s // 2) for c, s, f in zip(p, size, buffer.scale_factor))
             roi = Roi(offset, size)
             if buffer.can_load_logical_roi(roi):
-                buffer.load_logical_roi(roi)
+                if asynchronous:
+                    pieces = buffer.begin_async_load(roi)
+                    if pieces:
+                        jobs.append((buffer, pieces))
+                else:
+                    buffer.load_logical_roi(roi)
+        if jobs:
+            self._submit_uploads(jobs)
+
+    # -- asynchronous streaming ------------------------------------------------------
+    def _submit_uploads(self, jobs):
+        import queue
+        import threading
+
+        self._rings.handle                                # create the context on this thread
+        if self._worker is None:
+            self._jobs = queue.Queue()
+
+            def run():
+                while True:
+                    item = self._jobs.get()
+                    if item is None:
+                        return
+                    try:
+                        for buffer, pieces in item:
+                            for buffer_roi, logical_roi in pieces:
+                                buffer.load_into_buffer(buffer_roi, logical_roi)
+                        N.check(N.lib().svr_mark_uploads(self._rings.handle), "svr_mark_uploads")
+                    except BaseException as exc:  # surfaced by poll_uploads on the render thread
+                        self._worker_error = exc
+                    finally:
+                        self._inflight.append(item)
+
+            self._worker = threading.Thread(target=run, name="svr-upload", daemon=True)
+            self._worker.start()
+        self._submitted += 1
+        self._jobs.put(jobs)
+
+    def poll_uploads(self, wait: bool = False) -> bool:
+        """Publish the full ROI of every asynchronous load whose chunks have landed in HBM.
+        Returns True when nothing is in flight any more."""
+        import time
+
+        while True:
+            if self._worker_error is not None:
+                err, self._worker_error = self._worker_error, None
+                raise err
+            while self._inflight and self._submitted > self._completed:
+                pending = C.c_int(0)
+                N.check(N.lib().svr_uploads_pending(self._rings.handle, C.byref(pending)), "svr_uploads_pending")
+                if pending.value:
+                    break
+                for buffer, _ in self._inflight.pop(0):
+                    buffer.finish_async_load()
+                self._completed += 1
+            if self._submitted == self._completed or not wait:
+                return self._submitted == self._completed
+            time.sleep(0.0002)
 
     # -- the draw --------------------------------------------------------------
     def _push_material(self):
@@ -250,6 +318,8 @@ class SubVolume(_HasWorld):
     def prepare(self):
         """Push pending uniforms (material, per-LOD ROI/scale) to the device."""
         handle = self._rings.handle  # creates the context on first use
+        if self._submitted != self._completed:
+            self.poll_uploads()
         self._push_material()
         for b in self.wrapping_buffers:
             b._push_state()

@@ -175,6 +175,7 @@ class WrappingBuffer:
         self.uniform_buffer = _UniformView(self)
 
         self._roi_px: Roi | None = None
+        self._pending_async = None
         self._current_logical_roi_in_chunks: Roi | None = None
         self._scale_factor = (1.0, 1.0, 1.0)
         self._state_dirty = True
@@ -269,6 +270,43 @@ class WrappingBuffer:
         for buffer_roi, logical_roi in pieces:
             self.load_into_buffer(buffer_roi, logical_roi)
         self.publish()
+
+    def begin_async_load(self, logical_roi_in_pixels: Roi):
+        """First half of an asynchronous ``load_logical_roi``: plan the load, publish the SHRUNK ROI
+        (old ROI intersected with the new one) and return the upload pieces for a worker thread.
+
+        The ring slots the new chunks will overwrite belong to chunks outside that intersection, so
+        renders enqueued from now on never read a slot while it is being rewritten (the tearing the
+        reference documents in FUTURE.md:60-67); coarser LODs cover the gap meanwhile.  Returns
+        ``None`` for the silent no-op cases and while a previous asynchronous load is still in flight.
+        """
+        if self._pending_async is not None:
+            return None
+        plan = self.plan_logical_roi(logical_roi_in_pixels)
+        if plan is None:
+            return None
+        snapped, in_chunks, pieces = plan
+        if not pieces:                                   # nothing new to fetch: plain state change
+            self._current_logical_roi_in_pixels = snapped
+            self._current_logical_roi_in_chunks = in_chunks
+            return None
+        old = self._roi_px
+        shrunk = None
+        if old is not None:
+            inter = old.intersect(snapped)
+            shrunk = None if inter.empty else inter
+        self._current_logical_roi_in_pixels = shrunk      # what the sampler may see while chunks stream in
+        self._current_logical_roi_in_chunks = in_chunks   # what will be resident: later plans diff against it
+        self._pending_async = (snapped, pieces)
+        return pieces
+
+    def finish_async_load(self):
+        """Second half: all chunks are in HBM — publish the full new ROI."""
+        if self._pending_async is None:
+            return
+        snapped, _ = self._pending_async
+        self._pending_async = None
+        self._current_logical_roi_in_pixels = snapped
 
     def publish(self):
         """Order the uploads before later renders and push the new ROI uniform."""

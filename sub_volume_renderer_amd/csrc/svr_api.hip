@@ -67,6 +67,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->have_published = false; c->colors_dev = nullptr; c->colors_cap = 0; c->material_set = false;
     c->variant = 0; c->slot_bytes = 0; c->next_slot = 0; c->ev_a = c->ev_b = nullptr;
     c->render_done = nullptr; c->render_pending = false;
+    c->uploads_marker = nullptr; c->marker_set = false;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
@@ -77,6 +78,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->uploads_published, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->uploads_marker, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
         svr_set_error("svr_create: stream/event creation failed");
         return fail(SVR_ERR_HIP);
@@ -129,6 +131,7 @@ int svr_destroy(svr_ctx* c) {
     if (c->colors_dev) (void)hipFree(c->colors_dev);
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
     if (c->render_done) (void)hipEventDestroy(c->render_done);
+    if (c->uploads_marker) (void)hipEventDestroy(c->uploads_marker);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->render_stream) (void)hipStreamDestroy(c->render_stream);
@@ -206,10 +209,7 @@ static int check_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t
 // about to overwrite: order the upload stream behind it (the reference gets this
 // ordering from running everything on one queue).
 static int uploads_after_render(svr_ctx* c) {
-    if (c->render_pending) {
-        SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->render_done, 0));
-        c->render_pending = false;
-    }
+    if (c->render_pending.exchange(false)) SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->render_done, 0));
     return SVR_OK;
 }
 
@@ -324,6 +324,25 @@ int svr_publish_uploads(svr_ctx* c) {
     DeviceGuard guard(c->device);
     SVR_HIP_TRY(hipEventRecord(c->uploads_published, c->upload_stream));
     c->have_published = true;
+    return SVR_OK;
+}
+
+int svr_mark_uploads(svr_ctx* c) {
+    SVR_REQUIRE(c, "svr_mark_uploads: null ctx");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipEventRecord(c->uploads_marker, c->upload_stream));
+    c->marker_set = true;
+    return SVR_OK;
+}
+
+int svr_uploads_pending(svr_ctx* c, int* pending) {
+    SVR_REQUIRE(c && pending, "svr_uploads_pending: null argument");
+    *pending = 0;
+    if (!c->marker_set) return SVR_OK;
+    DeviceGuard guard(c->device);
+    const hipError_t e = hipEventQuery(c->uploads_marker);
+    if (e == hipErrorNotReady) { *pending = 1; return SVR_OK; }
+    SVR_HIP_TRY(e);
     return SVR_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -108,7 +109,9 @@ struct svr_ctx {
     int next_slot;
     hipEvent_t ev_a, ev_b;           // timing
     hipEvent_t render_done;          // recorded after the last enqueued render
-    bool       render_pending;
+    std::atomic<bool> render_pending;
+    hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
+    std::atomic<bool> marker_set;
 };
 
 // error plumbing -------------------------------------------------------------

@@ -103,8 +103,10 @@ def pairs(n=3, base=32):
 def test_subvolume_signature():
     names = list(inspect.signature(SubVolume.__init__).parameters)[1:5]
     assert names == ["material", "data_segmentation_pairs", "buffer_shape_in_chunks", "chunk_shape_in_pixels"]
-    names = list(inspect.signature(SubVolume.center_on_position).parameters)[1:]
-    assert names == ["position", "sizes"]
+    params = inspect.signature(SubVolume.center_on_position).parameters
+    assert list(params)[1:3] == ["position", "sizes"]                      # _wobject.py:135-139
+    assert params["asynchronous"].kind is inspect.Parameter.KEYWORD_ONLY   # extension, off by default
+    assert params["asynchronous"].default is False
     names = list(inspect.signature(WrappingBuffer.__init__).parameters)[1:6]
     assert names == ["backing_data", "segmentations", "shape_in_chunks", "chunk_shape_in_pixels", "scale_factor"]
 

@@ -207,3 +207,50 @@ def test_material_update_takes_effect():
     scene.spec.material["colors"] = [(0.9, 0.5, 1.0), (0.1, 0.0, 1.0)]       # s == 0 branch of hsv_to_rgb
     m.colors = scene.spec.material["colors"]
     check(scene)
+
+
+def test_async_streaming_protocol_never_tears():
+    """center_on_position(asynchronous=True): after every call the frame must equal the oracle for the
+    ROI state the product has PUBLISHED (shrunk = old & new while chunks stream in, then the full new
+    ROI), whatever the timing; the final state equals the synchronous result."""
+    import torch
+
+    from oracle import ring_oracle as R
+
+    spec = testing.synthetic_spec(64, 96, 64, inside=True)
+    scene = testing.build(spec)
+    vol = scene.volume
+    orac = lmip.oracle_volume(spec)                      # applies the same initial center_on_position
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    shrunk_seen = 0
+    for k in range(1, 9):
+        p = eye + d * 6.0 * k
+        spec.cam_position = tuple(p)
+        spec.cam_target = tuple(p + d)
+        scene.camera = spec.camera()
+        vol.center_on_position(tuple(p), asynchronous=True)
+        orac.center_on_position(tuple(p))                # oracle textures now hold the new chunks too
+        for attempt in range(2):                         # frame 0: maybe still streaming; frame 1: after landing
+            if attempt == 1:
+                vol.poll_uploads(wait=True)
+            res = vol.render(scene.camera, spec.width, spec.height, count_steps=True)
+            torch.cuda.synchronize()
+            rings = lmip.rings_of(orac)
+            for ring, b, ob in zip(rings, vol.wrapping_buffers, orac.wrapping_buffers):
+                u = b.uniform_buffer.data                # what the product published for THIS frame
+                ring["offset"] = tuple(int(v) for v in u["current_logical_offset_in_pixels"])
+                ring["shape"] = tuple(int(v) for v in u["current_logical_shape_in_pixels"])
+                if ob.current_logical_roi_in_pixels is not None and tuple(ring["shape"]) != tuple(ob.uniform()["shape"]):
+                    shrunk_seen += 1
+            ref = lmip.render(rings, spec.matrices(), orac.volume_dimensions_shader, spec.material,
+                              spec.width, spec.height)
+            rep = testing.compare(res, ref)
+            assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], (k, attempt, rep)
+            assert rep["rgba_max_rel"] <= RGBA_TOL
+        # after landing, the published state is exactly the synchronous one
+        for b, ob in zip(vol.wrapping_buffers, orac.wrapping_buffers):
+            got = b._current_logical_roi_in_pixels
+            assert (None if got is None else (tuple(got.offset), tuple(got.shape))) == ob.current_logical_roi_in_pixels
+            np.testing.assert_array_equal(b.texture.data, ob.texture)
