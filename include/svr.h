@@ -198,7 +198,10 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
 /* kernel variant selector for A/B measurement (results are identical for every value):
  * bits 0-3  kernel: 0 = default span march, 1 = straightforward one-load-per-step march
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
- * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave heuristic; u8 rings only) */
+ * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
+ * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
+ * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
+ * bits 24-31 mask of LODs allowed to stage bricks (0 = default 0xFE: all but the finest) */
 int  svr_set_variant(svr_ctx* ctx, int variant);
 
 /* ---- multi-GPU helper: scatter a rank-major gathered stripe buffer back

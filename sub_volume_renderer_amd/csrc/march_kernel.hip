@@ -292,7 +292,8 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
         return inc ? v >= thresh : v < thresh;
     };
     if (!(step > 0.0f) && !(step < 0.0f)) return pred(0) ? 0 : n;
-    const float guess = ceilf(((float)thresh / (size * scale) - start) / step);
+    // only a starting point for the exact monotone fix-up below: fast reciprocals are fine
+    const float guess = ceilf(((float)thresh * __frcp_rn(size * scale) - start) * __frcp_rn(step));
     int j = (int)fminf(fmaxf(guess, 0.0f), (float)n);
 #pragma nounroll
     while (j > 0 && pred(j - 1)) --j;
@@ -398,8 +399,25 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // wave tile = (1 << lw) x (64 >> lw) pixels; a block is 2 x 2 wave tiles
     const int lw = P.tile_log2w;
-    const int c = ((tile_x * 2 + (wave & 1)) << lw) + (lane & ((1 << lw) - 1));
-    const int r = ((tile_y * 2 + (wave >> 1)) << (6 - lw)) + (lane >> lw);
+    const int c0 = (tile_x * 2 + (wave & 1)) << lw, r0 = (tile_y * 2 + (wave >> 1)) << (6 - lw);
+    // Lane order inside the wave tile.  The L1 serves a gather one lane-quad at a time and merges the
+    // four lanes only when they hit the same line, so consecutive lanes should be neighbours along the
+    // volume's contiguous axis x.  On screen, x points towards its vanishing point (the clip-space image
+    // of (1,0,0,0)): run consecutive lanes along screen rows if that direction is mostly horizontal at
+    // this tile, along screen columns otherwise.  A permutation of which lane renders which pixel only.
+    int lc = lane & ((1 << lw) - 1), lr = lane >> lw;
+    {
+        const float pcx = (float)(P.frame.x0 + c0) + 0.5f * (float)(1 << lw);
+        const float pcy = (float)(P.frame.y0 + (r0 / P.frame.band_h) * P.frame.band_pitch + (r0 % P.frame.band_h)) +
+                          0.5f * (float)(64 >> lw);
+        const float ncx = 2.0f * pcx / (float)P.frame.frame_w - 1.0f;
+        const float ncy = 1.0f - 2.0f * pcy / (float)P.frame.frame_h;
+        const float dx = (P.xdir[0] - ncx * P.xdir[3]) * (float)P.frame.frame_w;
+        const float dy = (P.xdir[1] - ncy * P.xdir[3]) * (float)P.frame.frame_h;
+        if (P.orient && fabsf(dy) > fabsf(dx)) { lr = lane & ((64 >> lw) - 1); lc = lane >> (6 - lw); }
+    }
+    const int c = c0 + lc;
+    const int r = r0 + lr;
     const bool inside = c < P.frame.out_w && r < P.frame.out_h;
     const size_t o = (size_t)r * (size_t)P.frame.out_w + (size_t)c;
     const int x = P.frame.x0 + c;
@@ -480,15 +498,25 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     int code = NL, E = 0;
     uint32_t Kc = 0xFFFFFFFFu;
 
-    // Wave-static routing of fast runs (u8 rings): LDS bricks pay when the samples a wave fetches
-    // together fall into many different memory rows, i.e. when the march advances mostly along x
-    // (equal-iteration surfaces are then roughly perpendicular to x).  P.brick: 0 never, 1 auto, 2 always.
+    // Wave-static routing of fast runs (u8 rings).  LDS bricks pay when the samples a wave fetches
+    // together fall into many different lines per lane-quad (the L1 does one lookup per distinct line
+    // of each quad).  Probe it: at one iteration, count how many lanes hit a line that no lower lane of
+    // their quad hits; > kBrickQuadLines lookups per load -> stage bricks.  P.brick: 0 never, 1 probe, 2 always.
     bool use_brick = false;
     if (ESH == 0 && P.brick) {
-        const float vx = fabsf(R.step.x * P.size[0]), vy = fabsf(R.step.y * P.size[1]), vz = fabsf(R.step.z * P.size[2]);
-        const unsigned long long fm = __builtin_amdgcn_ballot_w64(frag);
-        const unsigned long long xm = __builtin_amdgcn_ballot_w64(frag && vx >= fmaxf(vy, vz));
-        use_brick = P.brick >= 2 || 2 * __builtin_popcountll(xm) > __builtin_popcountll(fm);
+        const float pf = (float)min(max(nsteps - 1, 0), 256);
+        const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> 7;       // 128 voxels per line
+        const int qy = (int)((R.start.y + pf * R.step.y) * P.size[1]);
+        const int qz = (int)((R.start.z + pf * R.step.z) * P.size[2]);
+        const int key = frag ? ((qz * 4099 + qy) * 64 + (qx & 63)) : -1 - lane;
+        const int k0 = __builtin_amdgcn_update_dpp(key, key, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
+        const int k1 = __builtin_amdgcn_update_dpp(key, key, 0x55, 0xF, 0xF, false);   // [1,1,1,1]
+        const int k2 = __builtin_amdgcn_update_dpp(key, key, 0xAA, 0xF, 0xF, false);   // [2,2,2,2]
+        const int q = lane & 3;
+        const bool fresh = frag && (q == 0 || (key != k0 && (q == 1 || (key != k1 && (q == 2 || key != k2)))));
+        const int lines = __builtin_popcountll(__builtin_amdgcn_ballot_w64(fresh));
+        const int quads = __builtin_popcountll(__builtin_amdgcn_ballot_w64(frag && q == 0)) + 1;
+        use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;               // lookups per full wave-load
     }
     const int wave_lds = wave * kBrickBytes;
 
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 // slab length: about 12 ring voxels of travel (coarser LODs advance less per iteration)
                 const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
                 const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
-                while (use_brick && run >= slab / U && (L.ring[0] & 15u) == 0u) {
+                while (use_brick && (P.brick_lod_mask >> l & 1) && run >= slab / U && (L.ring[0] & 15u) == 0u) {
                     const bool live = alive && !finished;
                     const float fa = (float)n, fb = (float)(n + slab - 1);
                     const int ax_ = (int)((R.start.x + fa * R.step.x) * ssx);
@@ -620,29 +648,31 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const int ny = hy - ly + 1, nz = hz - lz + 1;
                     const int groups = (ny * nz) << lgx;
                     if (ny >= 512 || groups * 16 > kBrickBytes) { use_brick = false; break; }   // does not fit: direct
-                    // rows advance by `rs` per 1-KiB load; (yy, zz) and the ring row track that incrementally
-                    const int rs = 64 >> lgx;
-                    const int qz = rs / ny, ry = rs - qz * ny;          // uniform
-                    const int row0 = lane >> lgx;
-                    int zz = (int)((float)row0 * (1.0f / (float)ny));    // row0 < 64: exact after the two fix-ups
-                    zz -= (zz * ny > row0) ? 1 : 0;
-                    zz += ((zz + 1) * ny <= row0) ? 1 : 0;
-                    int yy = row0 - zz * ny;
+                    // One load instruction per (z plane, chunk of 64 >> lgx rows): a lane's source offset is
+                    // a per-lane constant (its row y and 16-voxel group) plus a wave-uniform z term, so the
+                    // loop body is one VALU add.  Lanes beyond the plane's rows are masked off (an LDS-DMA
+                    // lane writes at base + lane*16, so inactive lanes simply leave their slot alone).
+                    const int rows_per = 64 >> lgx;
+                    const int ly_lane = lane >> lgx;
                     uint32_t wx = (uint32_t)(gx0 + ((lane & ((1 << lgx) - 1)) << 4) + L.addw[0]);
                     wx = min(wx, wx - L.ring[0]);
-                    const uint32_t src_x = L.base_bytes + wx;
-                    for (int g0 = 0; g0 < groups; g0 += 64) {
+                    const uint32_t plane_bytes = (uint32_t)(ny << (lgx + 4));
+                    const uint32_t zpitch = L.ring[1] * L.rx4;                       // bytes per ring z plane
+                    for (int yc = 0; yc < ny; yc += rows_per) {
+                        const int yy = yc + ly_lane;
                         uint32_t wy = (uint32_t)(ly + yy + L.addw[1]);
-                        uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);
                         wy = min(wy, wy - L.ring[1]);
-                        wz = min(wz, wz - L.ring[2]);
-                        uint32_t src = mad24(mad24(wz, L.ring[1], wy), L.rx4, src_x);
-                        if (g0 + lane >= groups) src = 0xFFFFFFF0u;        // range-checked: loads zeros
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rsrc, (__attribute__((address_space(3))) void*)(lds_all + wave_lds + g0 * 16),
-                            16, (int)src, 0, 0, 0);
-                        yy += ry; zz += qz;
-                        if (yy >= ny) { yy -= ny; zz += 1; }
+                        const uint32_t lane_src = mad24(wy, L.rx4, L.base_bytes + wx);
+                        const uint32_t lds_chunk = (uint32_t)wave_lds + (uint32_t)(yc << (lgx + 4));
+                        if (yy < ny) {
+                            for (int zz = 0; zz < nz; ++zz) {
+                                uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);      // wave-uniform
+                                wz = min(wz, wz - L.ring[2]);
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                    rsrc, (__attribute__((address_space(3))) void*)(lds_all + lds_chunk + zz * plane_bytes),
+                                    16, (int)(lane_src + wz * zpitch), 0, 0, 0);
+                            }
+                        }
                     }
                     // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
                     const uint32_t sh = (uint32_t)lgx + 4u;
@@ -658,7 +688,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             const uint32_t iy = (uint32_t)(int)((R.start.y + iter * R.step.y) * ssy);
                             const uint32_t iz = (uint32_t)(int)((R.start.z + iter * R.step.z) * ssz);
                             const uint32_t a = shl_add(mad24(iz, (uint32_t)ny, iy), sh, ix + bk);
-                            s[u] = (float)lds_all[a & (4 * kBrickBytes - 1)];
+                            s[u] = (float)lds_all[a];
                         }
                         lmip_batch(s, n, alive && !finished, false);
                         n += U;

@@ -420,6 +420,15 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     if ((c->variant & 15) == 1) lw = 3;                       // the simple kernel is 8x8 only
     P.tile_log2w = lw;
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
+    P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
+    P.orient = (c->variant & 1024) ? 0 : 1;
+    P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFE;   // measured: bricks pay in the coarser LODs (longer slabs, smaller boxes)
+    {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
+        const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
+        float wx[4];
+        mat_vec4(cam->world, ex, wx);
+        mat_vec4(P.pc, wx, P.xdir);
+    }
     const int bw = 2 << lw, bh = 2 * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     for (int l = 0; l < c->num_lods; ++l) {

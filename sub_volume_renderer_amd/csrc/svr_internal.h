@@ -61,7 +61,11 @@ struct MarchParams {
     // block -> tile mapping
     int32_t tiles_x, tiles_y;
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
-    int32_t brick;                 // 0 never / 1 per-wave heuristic / 2 always: LDS bricks (u8 rings only)
+    int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
+    int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l); default: every LOD but the finest
+    int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
+    int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
+    float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)
     int32_t lod_pow2[SVR_MAX_LODS];// 1: all three scale factors of the LOD are powers of two and the
                                    //    voxel indices fit the 24-bit multiplier (fast path eligible)
     LodParams lod[SVR_MAX_LODS];
