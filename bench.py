@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1024, help="volume edge (config 2: 1024)")
+    ap.add_argument("--volume-n", dest="n", type=int, default=1024, help="volume edge (config 2: 1024)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--camera", choices=["K1", "K2"], default="K1")
@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
                     help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
     ap.add_argument("--modes", default="full,lmip", help="march modes to time (full must be included)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo: rehearsal of the N>1 path when several ranks must "
+                         "share one GPU (bands are gathered through host memory; not a performance number)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled rows with the oracle")
     return ap.parse_args()
 
@@ -89,10 +92,16 @@ def main():
     if rank == 0:
         g.build_hip()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, ndev)           # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         dist.barrier()
 
     from sub_volume_renderer_amd import FrameRegion, Roi, _native as N, synth, testing
@@ -135,28 +144,52 @@ def main():
 
     # ---- outputs for the timed loop
     out = vol._outputs(region.out_h, region.out_w, False)
+    outs = [out]
+    if world > 1:
+        vol._out_cache = {}
+        outs.append(vol._outputs(region.out_h, region.out_w, False))        # double-buffered band outputs
+        out = outs[0]
+    last_frame = [None]
+    frame_no = [0]
 
     def frame():
-        res = vol.render(cam, W, H, region=region, out=out)
+        buf = outs[frame_no[0] % len(outs)]
+        frame_no[0] += 1
+        res = vol.render(cam, W, H, region=region, out=buf)
         if world > 1:
-            tiled.gather(res.rgba, dst=0, volume=vol)      # RCCL gather of the RGBA bands + un-tile kernel
+            if args.backend == "nccl":
+                # RCCL gather of this frame's RGBA bands, overlapped with the next frame's march;
+                # the previous frame is completed (wait + un-tile kernel) here
+                f = tiled.gather_pipelined(res.rgba, dst=0, volume=vol)
+            else:
+                f = tiled.gather(res.rgba.cpu(), dst=0)                     # rehearsal through host memory
+            if f is not None:
+                last_frame[0] = f
+
+    def drain():
+        if world > 1 and args.backend == "nccl":
+            f = tiled.flush(dst=0)
+            if f is not None:
+                last_frame[0] = f
 
     def timed(mode, steps, warmup):
         set_mode(mode == "full")
         for _ in range(warmup):
             frame()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):
             frame()
+        drain()                                          # the K-th frame's gather + un-tile are inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
@@ -298,6 +331,28 @@ def main():
             torch.cuda.synchronize()
             result["check"] = testing.compare(res, ref)
 
+    if rank == 0 and world > 1 and args.check:
+        set_mode(True)
+        frame_full = vol.render(cam, W, H, region=full_frame)
+        torch.cuda.synchronize()
+        set_mode(True)
+        frame()
+        drain()
+        torch.cuda.synchronize()
+        got = last_frame[0]
+        got = got.to(frame_full.rgba.device)
+        bad = (got != frame_full.rgba).any(dim=-1)
+        result["check"] = {"gathered_frame_equals_single_gpu_render": bool(torch.equal(got, frame_full.rgba)),
+                           "mismatched_pixels": int(bad.sum().item()),
+                           "coloured_pixels_gathered": int((got[..., :3].abs().sum(-1) > 0).sum().item()),
+                           "coloured_pixels_single": int((frame_full.rgba[..., :3].abs().sum(-1) > 0).sum().item()),
+                           "alpha1_gathered": int((got[..., 3] == 1).sum().item()),
+                           "alpha1_single": int((frame_full.rgba[..., 3] == 1).sum().item()),
+                           "mismatched_rows": [int(v) for v in torch.nonzero(bad.any(dim=1)).flatten()[:12].tolist()]}
+    elif world > 1 and args.check:
+        set_mode(True)
+        frame()
+        drain()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

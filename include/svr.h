@@ -191,8 +191,8 @@ int  svr_clear_lod(svr_ctx* ctx, int lod);
 /* ---- the draw: replaces renderer.render(scene, camera) for the
  * (SubVolume, SubVolumeMaterial) pair — vs_main.wgsl:6-50 + fs_main.wgsl:4-101
  * + raycast.wgsl:11-88 + sample_vol.wgsl + hsv_selection.wgsl.
- * Enqueued on `stream` (a hipStream_t passed as void*; NULL = the context's
- * own render stream).  Asynchronous. */
+ * Enqueued on `stream` (a hipStream_t passed as void*; NULL = the device's default
+ * stream), i.e. ordered with the caller's other work on that stream.  Asynchronous. */
 int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
                 const svr_outputs* out, void* stream);
 /* kernel variant selector for A/B measurement (results are identical for every value):
@@ -217,6 +217,11 @@ int  svr_sync(svr_ctx* ctx);                 /* both streams idle */
 int  svr_sync_uploads(svr_ctx* ctx);         /* upload stream idle */
 /* raw device pointers of one LOD's ring textures (for diagnostics / RCCL) */
 int  svr_lod_device_ptrs(svr_ctx* ctx, int lod, void** density, void** labels);
+
+/* diagnostics: batch census accumulated by instrumented renders (outputs.steps != NULL):
+ * [0] general batches, [1] direct fast batches, [2] brick batches, [3] brick slabs, [4] runs,
+ * [5] all-zero batches, [6] waves; batches are per wave, 8 iterations each */
+int  svr_debug_counters(svr_ctx* ctx, uint32_t out[8], int reset);
 
 /* timing helper: run `iters` back-to-back renders on the context's render
  * stream bracketed by HIP events on that same stream; returns the average

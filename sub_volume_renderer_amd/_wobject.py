@@ -139,6 +139,9 @@ class SubVolume(_HasWorld):
         self.volume_dimensions = base_data.shape
         self._material_version_pushed = -1
         self._out_cache = {}
+        self._cam_cache = None
+        self._frame_cache = {}
+        self._ob_cache = {}
         self._worker = None
         self._worker_error = None
         self._inflight = []
@@ -277,8 +280,22 @@ class SubVolume(_HasWorld):
         N.check(N.lib().svr_set_material(self._rings.handle, C.byref(cm)), "svr_set_material")
         self._material_version_pushed = m._version
 
+    def _camera_key(self, camera):
+        w, cw = self.world, camera.world
+        return (id(camera), w._position.tobytes(), w._rot.tobytes(), w._scale.tobytes(),
+                cw._position.tobytes(), cw._rot.tobytes(), cw._scale.tobytes(),
+                camera.fov, camera.aspect, camera.zoom, camera.near_far, self._volume_dimensions.tobytes())
+
     def camera_block(self, camera) -> "N.Camera":
-        """The uniforms vs_main/fs_main read, as ``svr_camera``."""
+        """The uniforms vs_main/fs_main read, as ``svr_camera`` (cached while nothing moved)."""
+        key = self._camera_key(camera) if hasattr(camera, "near_far") else None
+        if key is not None and self._cam_cache is not None and self._cam_cache[0] == key:
+            return self._cam_cache[1]
+        cb = self._camera_block_uncached(camera)
+        self._cam_cache = (key, cb)
+        return cb
+
+    def _camera_block_uncached(self, camera) -> "N.Camera":
         cb = N.Camera()
         cb.world = N.mat_to_c(self.world.matrix)
         cb.world_inv = N.mat_to_c(self.world.inverse_matrix)
@@ -291,7 +308,11 @@ class SubVolume(_HasWorld):
 
     def frame_block(self, width: int, height: int, region: FrameRegion | None) -> "N.Frame":
         r = region or FrameRegion.full(width, height)
-        fb = N.Frame()
+        key = (width, height, r.x0, r.y0, r.out_w, r.out_h, r.band_h, r.band_pitch)
+        fb = self._frame_cache.get(key)
+        if fb is not None:
+            return fb
+        fb = self._frame_cache[key] = N.Frame()
         fb.frame_w, fb.frame_h = int(width), int(height)
         fb.x0, fb.y0, fb.out_w, fb.out_h = int(r.x0), int(r.y0), int(r.out_w), int(r.out_h)
         fb.band_h = int(r.band_h or r.out_h)
@@ -339,12 +360,20 @@ class SubVolume(_HasWorld):
         cb = self.camera_block(camera)
         fb = self.frame_block(width, height, region)
         res = out or self._outputs(fb.out_h, fb.out_w, count_steps)
-        ob = N.Outputs()
-        ob.rgba = res.rgba.data_ptr()
-        ob.depth = res.depth.data_ptr() if res.depth is not None else None
-        ob.label = res.label.data_ptr() if res.label is not None else None
-        ob.flags = res.flags.data_ptr() if res.flags is not None else None
-        ob.steps = res.steps.data_ptr() if (count_steps and res.steps is not None) else None
+        okey = (id(res), bool(count_steps))
+        cached = self._ob_cache.get(okey)
+        if cached is not None and cached[0] is res:
+            ob = cached[1]
+        else:
+            ob = N.Outputs()
+            ob.rgba = res.rgba.data_ptr()
+            ob.depth = res.depth.data_ptr() if res.depth is not None else None
+            ob.label = res.label.data_ptr() if res.label is not None else None
+            ob.flags = res.flags.data_ptr() if res.flags is not None else None
+            ob.steps = res.steps.data_ptr() if (count_steps and res.steps is not None) else None
+            if len(self._ob_cache) > 8:
+                self._ob_cache.clear()
+            self._ob_cache[okey] = (res, ob)
         if stream is None:
             stream = torch.cuda.current_stream(self._rings.device).cuda_stream
         N.check(

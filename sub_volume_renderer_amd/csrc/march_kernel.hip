@@ -520,6 +520,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     }
     const int wave_lds = wave * kBrickBytes;
 
+    // diagnostics of the instrumented build (COUNT): wave-level batch census
+    int c_general = 0, c_direct = 0, c_brick = 0, c_slabs = 0, c_runs = 0, c_zero = 0;
     int n = 0;                                       // wave-uniform: every ray starts at iteration 0
     while (true) {
         const bool alive = !finished && n < nsteps;
@@ -563,8 +565,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         if (first < NL && !P.lod_pow2[first < NL ? first : 0]) lane_run = alive ? 0 : lane_run;   // fused constant needs 2^-k scales
         if (!alive) lane_run = 0x3fffffff;
         int run = wave_reduce<false>(lane_run);
+        if (COUNT) ++c_runs;
 
         if (run <= 0) {
+            if (COUNT) ++c_general;
             // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
             float s[U];
             uint32_t off[U];
@@ -600,6 +604,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 #pragma unroll
             for (int u = 0; u < U; ++u) s[u] = 0.0f;
             for (; run > 0; --run) {
+                if (COUNT) ++c_zero;
                 lmip_batch(s, n, alive && !finished, false);
                 n += U;
                 if (__builtin_amdgcn_ballot_w64(alive && !finished) == 0) break;
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     py.x = live ? (short)min(ay_, by_) : big; py.y = live ? (short)(-max(ay_, by_)) : big;
                     pz.x = live ? (short)min(az_, bz_) : big; pz.y = live ? (short)(-max(az_, bz_)) : big;
                     px = wave_min2(px); py = wave_min2(py); pz = wave_min2(pz);
+                    if (COUNT) ++c_slabs;
                     if (px.x == big) { run = 0; break; }                 // no live lane left
                     const int lx = px.x, hx = -(int)px.y, ly = py.x, hy = -(int)py.y, lz = pz.x, hz = -(int)pz.y;
                     // 16-voxel groups aligned in RING space, so a group never straddles the wrap
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
                     const uint32_t sh = (uint32_t)lgx + 4u;
                     const uint32_t bk = (uint32_t)wave_lds - (uint32_t)((((lz * ny + ly) << sh) + gx0));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!P.dbg_nowait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     for (int k = 0; k < slab / U; ++k) {
                         float s[U];
                         const float basef = (float)n;
@@ -692,6 +698,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         }
                         lmip_batch(s, n, alive && !finished, false);
                         n += U;
+                        if (COUNT) ++c_brick;
                     }
                     run -= slab / U;
                     asm volatile("" ::: "memory");      // the next slab's loads must not overtake these LDS reads
@@ -702,6 +709,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             for (; run > 0; --run) {
                 const bool live = alive && !finished;
                 if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+                if (COUNT) ++c_direct;
                 float s[U];
                 uint32_t off[U];
                 const float basef = (float)n;
@@ -726,6 +734,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         }
     }
 
+    if (COUNT && P.dbg && lane == 0) {
+        atomicAdd(P.dbg + 0, (uint32_t)c_general); atomicAdd(P.dbg + 1, (uint32_t)c_direct);
+        atomicAdd(P.dbg + 2, (uint32_t)c_brick);   atomicAdd(P.dbg + 3, (uint32_t)c_slabs);
+        atomicAdd(P.dbg + 4, (uint32_t)c_runs);    atomicAdd(P.dbg + 5, (uint32_t)c_zero);
+        atomicAdd(P.dbg + 6, 1u);
+    }
     Hit h;
     h.found = found; h.sample = samp; h.steps = steps;
     const float hit_f = (float)hit_i;

@@ -67,7 +67,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->have_published = false; c->colors_dev = nullptr; c->colors_cap = 0; c->material_set = false;
     c->variant = 0; c->slot_bytes = 0; c->next_slot = 0; c->ev_a = c->ev_b = nullptr;
     c->render_done = nullptr; c->render_pending = false;
-    c->uploads_marker = nullptr; c->marker_set = false;
+    c->uploads_marker = nullptr; c->marker_set = false; c->dbg_dev = nullptr;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
@@ -129,6 +129,7 @@ int svr_destroy(svr_ctx* c) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (c->colors_dev) (void)hipFree(c->colors_dev);
+    if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
     if (c->render_done) (void)hipEventDestroy(c->render_done);
     if (c->uploads_marker) (void)hipEventDestroy(c->uploads_marker);
@@ -412,6 +413,9 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
     P.num_lods = c->num_lods;
+    if (out->steps && !c->dbg_dev && hipMalloc((void**)&c->dbg_dev, 8 * sizeof(uint32_t)) == hipSuccess)
+        (void)hipMemset(c->dbg_dev, 0, 8 * sizeof(uint32_t));
+    P.dbg = out->steps ? c->dbg_dev : nullptr;
     P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
     // variant: bits 0-3 kernel kind (0 batched U=8, 1 simple, 2 batched U=4), bits 4-7 = 1 + log2 of the
     // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
@@ -422,6 +426,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
     P.orient = (c->variant & 1024) ? 0 : 1;
+    P.dbg_nowait = (c->variant & 2048) ? 1 : 0;
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFE;   // measured: bricks pay in the coarser LODs (longer slabs, smaller boxes)
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
@@ -470,7 +475,9 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     int rc = fill_params(c, cam, fr, out, P);
     if (rc) return rc;
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->render_stream;
+    // the caller's stream; NULL is the device's default stream (what torch.cuda.current_stream() is
+    // unless the caller switched streams), so the draw is ordered with the caller's other work on it
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(svr_launch_march(P, c->variant & 15, s));
     SVR_HIP_TRY(hipEventRecord(c->render_done, s));
@@ -504,7 +511,7 @@ int svr_untile_stripes(svr_ctx* c, const void* gathered, void* frame_out, int fr
     const int nbands = (frame_h + band_h - 1) / band_h;
     SVR_REQUIRE(out_h >= ((nbands + nranks - 1) / nranks) * band_h, "svr_untile_stripes: out_h too small for the frame");
     DeviceGuard guard(c->device);
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->render_stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);       // NULL = default stream, as in svr_render
     SVR_HIP_TRY(svr_launch_untile(gathered, frame_out, frame_w, frame_h, band_h, nranks, out_h, elem_bytes, s));
     return SVR_OK;
 }
@@ -521,6 +528,17 @@ int svr_sync_uploads(svr_ctx* c) {
     SVR_REQUIRE(c, "svr_sync_uploads: null ctx");
     DeviceGuard guard(c->device);
     SVR_HIP_TRY(hipStreamSynchronize(c->upload_stream));
+    return SVR_OK;
+}
+
+int svr_debug_counters(svr_ctx* c, uint32_t out[8], int reset) {
+    SVR_REQUIRE(c && out, "svr_debug_counters: null argument");
+    memset(out, 0, 8 * sizeof(uint32_t));
+    if (!c->dbg_dev) return SVR_OK;
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipDeviceSynchronize());
+    SVR_HIP_TRY(hipMemcpy(out, c->dbg_dev, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (reset) SVR_HIP_TRY(hipMemset(c->dbg_dev, 0, 8 * sizeof(uint32_t)));
     return SVR_OK;
 }
 

@@ -53,6 +53,7 @@ struct MarchParams {
     uint32_t* label;
     uint8_t*  flags;
     uint32_t* steps;
+    uint32_t* dbg;                 // batch census of the instrumented build (8 counters) or NULL
     // all LOD density rings live in ONE allocation so a single buffer resource
     // (32-bit byte offsets, hardware range check) addresses every LOD
     const void* density_all;
@@ -63,6 +64,7 @@ struct MarchParams {
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l); default: every LOD but the finest
+    int32_t dbg_nowait;            // timing experiment only (WRONG results): do not wait for the brick loads
     int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
     int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
     float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)
@@ -114,6 +116,7 @@ struct svr_ctx {
     hipEvent_t ev_a, ev_b;           // timing
     hipEvent_t render_done;          // recorded after the last enqueued render
     std::atomic<bool> render_pending;
+    uint32_t*  dbg_dev;              // 8 diagnostic counters (instrumented renders)
     hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
     std::atomic<bool> marker_set;
 };

@@ -60,6 +60,45 @@ class TiledFrame:
         dist.gather(local, None, dst=dst)
         return None
 
+    def gather_pipelined(self, local, dst: int = 0, volume=None):
+        """Like :meth:`gather`, but frame k's collective runs beside frame k+1's render: the gather is
+        started asynchronously into one of two buffer sets and finished (wait + un-tile) one call later.
+        Returns the PREVIOUS frame on ``dst`` (``None`` on the first call and on other ranks).  The
+        caller must render successive frames into alternating band buffers.  Call :meth:`flush` at the end."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return local
+        k = self._pipe_k = getattr(self, "_pipe_k", -1) + 1
+        slot = k & 1
+        if self.rank == dst:
+            if getattr(self, "_pipe_bufs", None) is None or self._pipe_bufs[0].shape[1:] != local.shape:
+                self._pipe_bufs = [torch.empty((self.world, *local.shape), dtype=local.dtype, device=local.device)
+                                   for _ in range(2)]
+                self._pipe_frames = [torch.empty((self.height, self.width, *local.shape[2:]), dtype=local.dtype,
+                                                 device=local.device) for _ in range(2)]
+            work = dist.gather(local, list(self._pipe_bufs[slot].unbind(0)), dst=dst, async_op=True)
+        else:
+            work = dist.gather(local, None, dst=dst, async_op=True)
+        prev = getattr(self, "_pipe_pending", None)
+        self._pipe_pending = (work, slot, volume)
+        return self._finish(prev, dst)
+
+    def _finish(self, pending, dst):
+        if pending is None:
+            return None
+        work, slot, volume = pending
+        work.wait()                                   # the current stream waits for that collective only
+        if self.rank != dst:
+            return None
+        return self.untile(self._pipe_bufs[slot], self._pipe_frames[slot], volume)
+
+    def flush(self, dst: int = 0):
+        """Finish the last pipelined gather; returns the last frame on ``dst``."""
+        pending, self._pipe_pending = getattr(self, "_pipe_pending", None), None
+        return self._finish(pending, dst)
+
     def untile(self, gathered, out, volume=None):
         """``gathered[rank, r]`` -> ``out[frame_row]``.  On the GPU this is the ``svr_untile_stripes``
         kernel; CPU tensors (gloo tests) are permuted with torch indexing."""

@@ -68,3 +68,40 @@ def test_band_partition_is_exact():
                     seen[y] += 1
         assert np.all(seen == 1)
     assert TiledFrame(8, 8, 0, 1).region == FrameRegion.full(8, 8)
+
+
+def _pipe_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, H, bh = 24, 21, 4
+        tf = TiledFrame(W, H, rank, world, bh)
+        rows = tf.frame_rows_of(rank)
+        frames = []
+        for k in range(4):                     # frame k: pixel value = 1000*k + 24*row + col (padding rows: -1)
+            band = torch.full((tf.rows_per_rank, W, 1), -1.0)
+            for r, y in enumerate(rows):
+                if y >= 0:
+                    band[r, :, 0] = 1000.0 * k + 24.0 * y + torch.arange(W, dtype=torch.float32)
+            f = tf.gather_pipelined(band, dst=0)
+            if rank == 0:
+                frames.append(None if f is None else f.clone())
+        last = tf.flush(dst=0)
+        if rank == 0:
+            frames.append(last.clone())
+            np.savez(out_path, **{f"f{i}": (np.zeros(0) if f is None else f.numpy()) for i, f in enumerate(frames)})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_returns_previous_frame(tmp_path):
+    """gather_pipelined overlaps frame k's collective with frame k+1's render: call k returns frame k-1."""
+    out = str(tmp_path / "pipe.npz")
+    mp.spawn(_pipe_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out)
+    assert got["f0"].size == 0                                   # nothing finished yet on the first call
+    yy, xx = np.meshgrid(np.arange(21), np.arange(24), indexing="ij")
+    for i in range(1, 5):                                        # call i returns frame i-1; flush returns frame 3
+        np.testing.assert_array_equal(got[f"f{i}"][..., 0], 1000.0 * (i - 1) + 24.0 * yy + xx)

@@ -254,3 +254,31 @@ def test_async_streaming_protocol_never_tears():
             got = b._current_logical_roi_in_pixels
             assert (None if got is None else (tuple(got.offset), tuple(got.shape))) == ob.current_logical_roi_in_pixels
             np.testing.assert_array_equal(b.texture.data, ob.texture)
+
+
+@pytest.mark.parametrize("world,band_h", [(2, 16), (8, 16), (3, 8)])
+def test_tiledframe_untile_paths_equal_full_render(world, band_h):
+    """The product's TiledFrame (band mapping + un-tile, GPU kernel and CPU path) reassembles the
+    per-rank band renders into exactly the single-GPU frame (one process plays every rank)."""
+    import torch
+
+    from sub_volume_renderer_amd.distributed import TiledFrame
+
+    W, H = 200, 135
+    scene = testing.build(testing.synthetic_spec(64, W, H))
+    whole = scene.volume.render(scene.camera, W, H)
+    torch.cuda.synchronize()
+    whole_rgba = whole.rgba.clone()
+    bands = []
+    for rank in range(world):
+        tf = TiledFrame(W, H, rank, world, band_h)
+        r = scene.volume.render(scene.camera, W, H, region=tf.region)
+        torch.cuda.synchronize()
+        bands.append(r.rgba.clone())
+    tf0 = TiledFrame(W, H, 0, world, band_h)
+    gathered = torch.stack(bands)
+    out_gpu = tf0.untile(gathered, torch.empty_like(whole_rgba), volume=scene.volume)
+    torch.cuda.synchronize()
+    assert torch.equal(out_gpu, whole_rgba)
+    out_cpu = tf0.untile(gathered.cpu(), torch.empty_like(whole_rgba).cpu())
+    assert torch.equal(out_cpu, whole_rgba.cpu())

@@ -32,8 +32,12 @@ for camname in cams:
         vol.material.lmip_threshold = float("inf") if mode == "full" else 127.5
         for v in variants:
             N.check(N.lib().svr_set_variant(vol._rings.handle, v), "variant")
+            dbg = (C.c_uint32 * 8)()
+            N.lib().svr_debug_counters(vol._rings.handle, dbg, 1)
             r = vol.render(cam, W, H, count_steps=True)
             torch.cuda.synchronize()
+            N.lib().svr_debug_counters(vol._rings.handle, dbg, 1)
+            census = list(dbg)
             steps = int(r.steps.to(torch.int64).sum().item())
             sig = (steps, int(r.label.to(torch.int64).sum().item()), float(r.rgba.double().sum().item()))
             ref.setdefault(mode, sig)
@@ -44,5 +48,5 @@ for camname in cams:
             ms = C.c_float(0)
             N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), 5, C.byref(ms)), "time")
             print(f"{camname:5s} {mode:5s} variant={v:#06x} steps={steps/1e6:8.1f}M {ms.value:7.3f} ms {steps/ms.value/1e6:7.1f} Gsteps/s "
-                  f"{4*steps/ms.value/1e6/8000*100:5.1f}% {same}", flush=True)
+                  f"{4*steps/ms.value/1e6/8000*100:5.1f}% {same} census[gen,dir,brick,slabs,runs,zero,waves]={census[:7]}", flush=True)
     del scene, vol
