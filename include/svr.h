@@ -212,6 +212,12 @@ int  svr_untile_stripes(svr_ctx* ctx, const void* gathered, void* frame_out,
                         int frame_w, int frame_h, int band_h, int nranks,
                         int out_h, int elem_bytes, void* stream);
 
+/* ---- LOD pyramid builder (device pointers): one 2x2x2 pooling step with the rules of the reference's
+ * offline builders — mode 0 = mean (scripts/create_mouse_multiscale.py:23-54; SVR_U8: floor(sum/8),
+ * SVR_F32: pairwise sum * 0.125), mode 1 = max (SVR_U32 labels, scripts/create_platynereis_multiscale.py:86-134).
+ * src_dims (x, y, z) must be even; dst has half the extent per axis.  Enqueued on `stream`. */
+int  svr_pool2x(int device, const void* src, void* dst, const int32_t src_dims[3], int dtype, int mode, void* stream);
+
 /* ---- sync */
 int  svr_sync(svr_ctx* ctx);                 /* both streams idle */
 int  svr_sync_uploads(svr_ctx* ctx);         /* upload stream idle */

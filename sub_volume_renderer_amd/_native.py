@@ -119,6 +119,7 @@ SIGNATURES = {
     "svr_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "svr_untile_stripes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "svr_pool2x": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, _I3, C.c_int, C.c_int, C.c_void_p]),
     "svr_sync": (C.c_int, [C.c_void_p]),
     "svr_sync_uploads": (C.c_int, [C.c_void_p]),
     "svr_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),

@@ -516,6 +516,17 @@ int svr_untile_stripes(svr_ctx* c, const void* gathered, void* frame_out, int fr
     return SVR_OK;
 }
 
+int svr_pool2x(int device, const void* src, void* dst, const int32_t src_dims[3], int dtype, int mode, void* stream) {
+    SVR_REQUIRE(src && dst && src_dims, "svr_pool2x: null argument");
+    for (int a = 0; a < 3; ++a)
+        SVR_REQUIRE(src_dims[a] >= 2 && (src_dims[a] & 1) == 0, "svr_pool2x: every source extent must be even and >= 2");
+    SVR_REQUIRE((dtype == SVR_U8 && mode == 0) || (dtype == SVR_F32 && mode == 0) || (dtype == SVR_U32 && mode == 1),
+                "svr_pool2x: supported: mean of u8 / f32 (mode 0), max of u32 (mode 1)");
+    DeviceGuard guard(device);
+    SVR_HIP_TRY(svr_launch_pool2x(src, dst, src_dims, dtype, mode, static_cast<hipStream_t>(stream)));
+    return SVR_OK;
+}
+
 int svr_sync(svr_ctx* c) {
     SVR_REQUIRE(c, "svr_sync: null ctx");
     DeviceGuard guard(c->device);

@@ -151,4 +151,6 @@ hipError_t svr_launch_gather(const void* ring_density, int ring_density_u8, cons
 hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,
                              int band_h, int nranks, int out_h, int elem_bytes, hipStream_t stream);
 
+hipError_t svr_launch_pool2x(const void* src, void* dst, const int32_t dims[3], int dtype, int mode, hipStream_t stream);
+
 size_t svr_dtype_size(int dtype);

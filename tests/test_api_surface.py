@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "svr.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(svr_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(svr_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_all_bound_and_exported():

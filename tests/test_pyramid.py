@@ -1,0 +1,60 @@
+"""GPU pyramid builder (svr_pool2x) against the restated pooling rules of the reference's offline scripts."""
+import numpy as np
+import pytest
+
+from oracle import pool_oracle
+from sub_volume_renderer_amd import synth
+
+
+def test_pool_oracle_matches_reference_numpy_expression():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 255, (8, 12, 20), dtype=np.uint8)
+    ref = a.reshape(4, 2, 6, 2, 10, 2).mean(axis=(1, 3, 5))          # create_mouse_multiscale.py:44-54
+    np.testing.assert_array_equal(pool_oracle.mean_u8(a), np.floor(ref).astype(np.uint8))
+    f = rng.random((8, 12, 20)).astype(np.float32)
+    np.testing.assert_allclose(pool_oracle.mean_f32(f), f.reshape(4, 2, 6, 2, 10, 2).mean(axis=(1, 3, 5)), rtol=1e-6)
+    lab = rng.integers(0, 2 ** 32 - 1, (8, 12, 20), dtype=np.uint32)
+    ref = np.zeros((4, 6, 10), np.uint32)
+    for i in range(4):
+        for j in range(6):
+            for k in range(10):
+                ref[i, j, k] = lab[2 * i:2 * i + 2, 2 * j:2 * j + 2, 2 * k:2 * k + 2].max()   # create_platynereis:113-130
+    np.testing.assert_array_equal(pool_oracle.max_u32(lab), ref)
+    # and the synthetic volumes' LODs follow the same rules
+    d0, l0 = synth.volume(32, 0)
+    d1, l1 = synth.volume(32, 1)
+    np.testing.assert_array_equal(pool_oracle.mean_u8(d0), d1)
+    np.testing.assert_array_equal(pool_oracle.max_u32(l0), l1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 12, 20), (64, 64, 64), (2, 2, 2), (6, 10, 30)])
+def test_pool2x_bit_exact(shape):
+    import torch
+
+    from sub_volume_renderer_amd.pyramid import pool2x
+
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 255, shape, dtype=np.uint8)
+    np.testing.assert_array_equal(pool2x(torch.from_numpy(a).cuda(), "mean").cpu().numpy(), pool_oracle.mean_u8(a))
+    f = (rng.random(shape) * 300 - 20).astype(np.float32)
+    np.testing.assert_array_equal(pool2x(torch.from_numpy(f).cuda(), "mean").cpu().numpy(), pool_oracle.mean_f32(f))
+    lab = rng.integers(0, 2 ** 32 - 1, shape, dtype=np.uint32)
+    got = pool2x(torch.from_numpy(lab.view(np.int32)).cuda(), "max").cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, pool_oracle.max_u32(lab))
+    with pytest.raises(ValueError):
+        pool2x(torch.zeros((3, 4, 4), dtype=torch.uint8, device="cuda"), "mean")
+
+
+@pytest.mark.gpu
+def test_build_pyramid_equals_synthetic_lods_and_streams_at_hbm_rate():
+    import torch
+
+    from sub_volume_renderer_amd.pyramid import build_pyramid
+
+    n = 256
+    d0, l0 = synth.volume(n, 0, xp=torch, device=torch.device("cuda", 0))
+    pairs = build_pyramid(d0, l0, 3)
+    for k in (1, 2):
+        dk, lk = synth.volume(n, k, xp=torch, device=torch.device("cuda", 0))
+        assert torch.equal(pairs[k][0], dk) and torch.equal(pairs[k][1], lk)
