@@ -201,7 +201,7 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
- * bits 24-31 mask of LODs allowed to stage bricks (0 = default 0xFE: all but the finest) */
+ * bits 24-31 mask of LODs allowed to stage bricks (0 = default: all) */
 int  svr_set_variant(svr_ctx* ctx, int variant);
 
 /* ---- multi-GPU helper: scatter a rank-major gathered stripe buffer back

@@ -343,6 +343,23 @@ __device__ __forceinline__ uint32_t shl_add_c(uint32_t a, uint32_t c) {         
 }
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// Voxel indices of TWO consecutive samples (iterations it, it+1) of one ray, with packed f32 math
+// (v_pk_mul_f32 / v_pk_add_f32 are IEEE-exact per component, no fusing): per axis
+//   ic = i32((start + f32(i) * step) * ss),   ss = size * scale (scale = 2^-k, see the caller)
+struct Idx2 { uint32_t x0, y0, z0, x1, y1, z1; };
+__device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float it, float ssx, float ssy, float ssz) {
+    const float2_t iter = { it, it + 1.0f };
+    const float2_t cx = (iter * R.step.x + R.start.x) * ssx;     // -ffp-contract=off: mul, add, mul
+    const float2_t cy = (iter * R.step.y + R.start.y) * ssy;
+    const float2_t cz = (iter * R.step.z + R.start.z) * ssz;
+    Idx2 r;
+    r.x0 = (uint32_t)(int)cx.x; r.x1 = (uint32_t)(int)cx.y;
+    r.y0 = (uint32_t)(int)cy.x; r.y1 = (uint32_t)(int)cy.y;
+    r.z0 = (uint32_t)(int)cz.x; r.z1 = (uint32_t)(int)cz.y;
+    return r;
+}
 
 // wave64 reduction of two packed 16-bit minima at once (v_pk_min_i16): returns (min lo, min hi)
 __device__ __forceinline__ short2_t wave_min2(short2_t v) {
@@ -434,6 +451,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     for (int l = 0; l < NL; ++l) {
         const LodParams& L = P.lod[l];
         int a = 0, b = nsteps, cr[3] = { 0, 0, 0 };
+        if (L.shape[0] == 0 || L.shape[1] == 0 || L.shape[2] == 0) {      // ROI is None: never in bounds
+            ev[l].a = 0; ev[l].b = 0; ev[l].cx = 0; ev[l].cy = 0; ev[l].cz = 0;
+            continue;
+        }
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const float st = ax == 0 ? R.start.x : (ax == 1 ? R.start.y : R.start.z);
@@ -449,7 +470,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 en = 0; ex = (lo <= v && v < hi) ? nsteps : 0;
             }
             a = max(a, en); b = min(b, ex);
-            cr[ax] = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], (int)L.ring[ax] - L.addw[ax]);
+            // the slot constant changes only if the ROI really wraps on this axis (wave-uniform test);
+            // otherwise encode "never": (n >= C) == inc must stay false
+            if (L.wrap0[ax] + L.shape[ax] > L.ring[ax])
+                cr[ax] = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], (int)L.ring[ax] - L.addw[ax]);
+            else
+                cr[ax] = inc ? nsteps : 0;
         }
         if (a >= b || L.shape[0] == 0) { a = 0; b = 0; }
         ev[l].a = a; ev[l].b = b; ev[l].cx = cr[0]; ev[l].cy = cr[1]; ev[l].cz = cr[2];
@@ -688,13 +714,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         float s[U];
                         const float basef = (float)n;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const float iter = basef + (float)u;
-                            const uint32_t ix = (uint32_t)(int)((R.start.x + iter * R.step.x) * ssx);
-                            const uint32_t iy = (uint32_t)(int)((R.start.y + iter * R.step.y) * ssy);
-                            const uint32_t iz = (uint32_t)(int)((R.start.z + iter * R.step.z) * ssz);
-                            const uint32_t a = shl_add(mad24(iz, (uint32_t)ny, iy), sh, ix + bk);
-                            s[u] = (float)lds_all[a];
+                        for (int u = 0; u < U; u += 2) {
+                            const Idx2 v = voxel_pair(R, basef + (float)u, ssx, ssy, ssz);
+                            const uint32_t a0 = shl_add(mad24(v.z0, (uint32_t)ny, v.y0), sh, v.x0 + bk);
+                            const uint32_t a1 = shl_add(mad24(v.z1, (uint32_t)ny, v.y1), sh, v.x1 + bk);
+                            s[u] = (float)lds_all[a0];
+                            s[u + 1] = (float)lds_all[a1];
                         }
                         lmip_batch(s, n, alive && !finished, false);
                         n += U;
@@ -714,12 +739,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 uint32_t off[U];
                 const float basef = (float)n;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float iter = basef + (float)u;
-                    const uint32_t ix = (uint32_t)(int)((R.start.x + iter * R.step.x) * ssx);
-                    const uint32_t iy = (uint32_t)(int)((R.start.y + iter * R.step.y) * ssy);
-                    const uint32_t iz = (uint32_t)(int)((R.start.z + iter * R.step.z) * ssz);
-                    off[u] = mad24(mad24(iz, L.ring[1], iy), L.rx4, shl_add_c<ESH>(ix, Kc));
+                for (int u = 0; u < U; u += 2) {
+                    const Idx2 v = voxel_pair(R, basef + (float)u, ssx, ssy, ssz);
+                    off[u] = mad24(mad24(v.z0, L.ring[1], v.y0), L.rx4, shl_add_c<ESH>(v.x0, Kc));
+                    off[u + 1] = mad24(mad24(v.z1, L.ring[1], v.y1), L.rx4, shl_add_c<ESH>(v.x1, Kc));
                 }
                 if (live) {
 #pragma unroll

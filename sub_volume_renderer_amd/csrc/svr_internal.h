@@ -63,7 +63,7 @@ struct MarchParams {
     int32_t tiles_x, tiles_y;
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
-    int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l); default: every LOD but the finest
+    int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
     int32_t dbg_nowait;            // timing experiment only (WRONG results): do not wait for the brick loads
     int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
     int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
