@@ -587,7 +587,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
         // ---- how many whole batches can every live lane run on one LOD with constant addressing?
         const int first = __builtin_amdgcn_readlane(code, (int)__builtin_ctzll(alive_mask));
-        int lane_run = (code == first) ? (E - n) / U : 0;          // E <= nsteps: all those samples exist
+        // a span that ends at the ray end may finish with a partial batch: its samples beyond nsteps
+        // are fetched from harmless (range-checked / LDS) addresses and masked in the LMIP update
+        int lane_run = (code == first) ? ((E == nsteps ? E - n + U - 1 : E - n) / U) : 0;
         if (first < NL && !P.lod_pow2[first < NL ? first : 0]) lane_run = alive ? 0 : lane_run;   // fused constant needs 2^-k scales
         if (!alive) lane_run = 0x3fffffff;
         int run = wave_reduce<false>(lane_run);
@@ -631,9 +633,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             for (int u = 0; u < U; ++u) s[u] = 0.0f;
             for (; run > 0; --run) {
                 if (COUNT) ++c_zero;
-                lmip_batch(s, n, alive && !finished, false);
+                const bool lv = alive && !finished && n < nsteps;
+                if (__builtin_amdgcn_ballot_w64(lv && n + U > nsteps) != 0) lmip_batch(s, n, lv, true);
+                else lmip_batch(s, n, lv, false);
                 n += U;
-                if (__builtin_amdgcn_ballot_w64(alive && !finished) == 0) break;
+                if (__builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) == 0) break;
             }
             continue;
         }
@@ -655,8 +659,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
                 const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
                 while (use_brick && (P.brick_lod_mask >> l & 1) && run >= slab / U && (L.ring[0] & 15u) == 0u) {
-                    const bool live = alive && !finished;
-                    const float fa = (float)n, fb = (float)(n + slab - 1);
+                    const bool live = alive && !finished && n < nsteps;
+                    const float fa = (float)n, fb = (float)min(n + slab - 1, nsteps - 1);   // last existing sample
                     const int ax_ = (int)((R.start.x + fa * R.step.x) * ssx);
                     const int ay_ = (int)((R.start.y + fa * R.step.y) * ssy);
                     const int az_ = (int)((R.start.z + fa * R.step.z) * ssz);
@@ -721,7 +725,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             s[u] = (float)lds_all[a0];
                             s[u + 1] = (float)lds_all[a1];
                         }
-                        lmip_batch(s, n, alive && !finished, false);
+                        {
+                            const bool lv = alive && !finished && n < nsteps;
+                            // keep the no-tail case a compile-time constant (its per-sample tests fold away)
+                            if (__builtin_amdgcn_ballot_w64(lv && n + U > nsteps) != 0) lmip_batch(s, n, lv, true);
+                            else lmip_batch(s, n, lv, false);
+                        }
                         n += U;
                         if (COUNT) ++c_brick;
                     }
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
             // ---- direct fast batches: texel offset = ((iz*Ry + iy)*Rx + ix)*es + Kc, U loads in flight
             for (; run > 0; --run) {
-                const bool live = alive && !finished;
+                const bool live = alive && !finished && n < nsteps;
                 if (__builtin_amdgcn_ballot_w64(live) == 0) break;
                 if (COUNT) ++c_direct;
                 float s[U];
@@ -751,7 +760,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) s[u] = 0.0f;
                 }
-                lmip_batch(s, n, live, false);
+                if (__builtin_amdgcn_ballot_w64(live && n + U > nsteps) != 0) lmip_batch(s, n, live, true);
+                else lmip_batch(s, n, live, false);
                 n += U;
             }
         }
