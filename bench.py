@@ -264,9 +264,16 @@ def main():
             }
         result["setup_s"] = {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)}
         if world == 1:
+            # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot be run from
+            # inside the process it profiles): profiles/r01/traffic.json, valid for the default workload only
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+            if os.path.exists(tpath) and (n, W, H, args.camera, args.variant, u8) == (1024, 1920, 1080, "K1", 0, True):
+                with open(tpath) as f:
+                    traffic = json.load(f)["traffic_bytes_per_launch"]
             result["roofline"] = {
                 "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": a_full / HBM_PEAK_GBS, "traffic": None,
+                "frac": a_full / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "march_span (full mode)", "kernel_ms": k_full,
                 "algorithmic_bytes": algo_bytes(counts["full"], W * H),
                 "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
