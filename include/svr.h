@@ -200,6 +200,7 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
+ * bits 11-12 instruction-count experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
  * bits 24-31 mask of LODs allowed to stage bricks (0 = default: all) */
 int  svr_set_variant(svr_ctx* ctx, int variant);

@@ -316,11 +316,22 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodParams& L, float
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
-// texel fetch through the range-checked buffer resource: f32 (ESH = 2) or u8 (ESH = 0) storage
+// Raw texel as fetched: f32 rings (ESH = 2) hold the sample itself, u8 rings (ESH = 0) the byte,
+// widened to f32 (exactly) only where the LMIP state machine needs the value.
+template <int ESH> struct Texel { typedef float type; };
+template <> struct Texel<0> { typedef uint32_t type; };
+__device__ __forceinline__ float texel_value(float t) { return t; }
+__device__ __forceinline__ float texel_value(uint32_t t) { return (float)t; }
+__device__ __forceinline__ float texel_abs(float t) { return fabsf(t); }
+__device__ __forceinline__ uint32_t texel_abs(uint32_t t) { return t; }
+__device__ __forceinline__ float texel_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ uint32_t texel_max(uint32_t a, uint32_t b) { return max(a, b); }
+
+// texel fetch through the range-checked buffer resource
 template <int ESH>
-__device__ __forceinline__ float fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
-    if (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
-    return (float)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, 0, 0);
+__device__ __forceinline__ typename Texel<ESH>::type fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
+    if constexpr (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+    else return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, 0, 0);
 }
 
 // a*b + c on the 24-bit integer multiplier (one full-rate-class VALU op); a, b < 2^24
@@ -349,8 +360,7 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 // (v_pk_mul_f32 / v_pk_add_f32 are IEEE-exact per component, no fusing): per axis
 //   ic = i32((start + f32(i) * step) * ss),   ss = size * scale (scale = 2^-k, see the caller)
 struct Idx2 { uint32_t x0, y0, z0, x1, y1, z1; };
-__device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float it, float ssx, float ssy, float ssz) {
-    const float2_t iter = { it, it + 1.0f };
+__device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float2_t iter, float ssx, float ssy, float ssz) {
     const float2_t cx = (iter * R.step.x + R.start.x) * ssx;     // -ffp-contract=off: mul, add, mul
     const float2_t cy = (iter * R.step.y + R.start.y) * ssy;
     const float2_t cz = (iter * R.step.z + R.start.z) * ssz;
@@ -360,6 +370,36 @@ __device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float it, float ssx, fl
     r.z0 = (uint32_t)(int)cz.x; r.z1 = (uint32_t)(int)cz.y;
     return r;
 }
+
+// Same chain, but y and z of each sample come back packed as y | z << 16 (the second convert writes
+// the upper half of the register directly): operand of the v_dot2_u32_u16 brick address below.
+// Indices are < 2^15 here (checked by the caller through the packed-i16 box reduction).
+struct Idx2p { uint32_t x0, yz0, x1, yz1; };
+__device__ __forceinline__ Idx2p voxel_pair_packed(const Ray& R, float2_t iter, float ssx, float ssy, float ssz) {
+    const float2_t cx = (iter * R.step.x + R.start.x) * ssx;
+    const float2_t cy = (iter * R.step.y + R.start.y) * ssy;
+    const float2_t cz = (iter * R.step.z + R.start.z) * ssz;
+    Idx2p r;
+    r.x0 = (uint32_t)(int)cx.x; r.x1 = (uint32_t)(int)cx.y;
+    r.yz0 = (uint32_t)(int)cy.x; r.yz1 = (uint32_t)(int)cy.y;
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r.yz0) : "v"(cz.x));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r.yz1) : "v"(cz.y));
+    return r;
+}
+// i32(v.x) | i32(v.y) << 16 with the halves ordered (smaller, larger): `up` says v.x <= v.y
+__device__ __forceinline__ uint32_t halves_min_max(float2_t v, bool up) {
+    uint32_t ab = (uint32_t)(int)v.x;
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(ab) : "v"(v.y));
+    return up ? ab : __builtin_amdgcn_alignbit(ab, ab, 16);
+}
+// a.lo * b.lo + a.hi * b.hi + c on 16-bit halves (one VALU op)
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+// a register with no defined value and no instruction (lanes whose value is never looked at)
+template <typename T> __device__ __forceinline__ T undefined_value() { T v; asm volatile("" : "=v"(v)); return v; }
 
 // wave64 reduction of two packed 16-bit minima at once (v_pk_min_i16): returns (min lo, min hi)
 __device__ __forceinline__ short2_t wave_min2(short2_t v) {
@@ -446,6 +486,16 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     const int nsteps = frag ? R.nsteps : 0;
 
     // ---- exact per-LOD event iterations
+    // ic is monotone along the ray, so its values at the first and last sample bound every other
+    // sample: a threshold outside that range is crossed at iteration 0 or never, and the search
+    // (first_cross) runs only for thresholds some lane of the wave really crosses.
+    float d0[3], d1[3];                       // data coords (sample_vol.wgsl:6) of samples 0 and nsteps-1
+    {
+        const float lastf = (float)(nsteps - 1);
+        d0[0] = (R.start.x + 0.0f * R.step.x) * P.size[0];  d1[0] = (R.start.x + lastf * R.step.x) * P.size[0];
+        d0[1] = (R.start.y + 0.0f * R.step.y) * P.size[1];  d1[1] = (R.start.y + lastf * R.step.y) * P.size[1];
+        d0[2] = (R.start.z + 0.0f * R.step.z) * P.size[2];  d1[2] = (R.start.z + lastf * R.step.z) * P.size[2];
+    }
     LodEvents ev[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -459,21 +509,33 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         for (int ax = 0; ax < 3; ++ax) {
             const float st = ax == 0 ? R.start.x : (ax == 1 ? R.start.y : R.start.z);
             const float sp = ax == 0 ? R.step.x : (ax == 1 ? R.step.y : R.step.z);
-            const int lo = L.off[ax], hi = L.off[ax] + (int)L.shape[ax];
-            const int jlo = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], lo);
-            const int jhi = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], hi);
-            // increasing: inside on [jlo, jhi); decreasing: inside on [jhi, jlo)
             const bool inc = sp > 0.0f;
+            const int v0 = (int)(d0[ax] * L.scale[ax]), v1 = (int)(d1[ax] * L.scale[ax]);   // ic(0), ic(nsteps-1)
+            // == first_cross(nsteps, st, sp, size, scale, T): pred(0) -> 0; !pred(nsteps-1) -> nsteps
+            auto cross = [&](int T) {
+                const bool p0 = inc ? v0 >= T : v0 < T;
+                const bool p1 = inc ? v1 >= T : v1 < T;
+                int j = p0 ? 0 : nsteps;
+                const bool need = !p0 && p1;
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                    const int js = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], T);
+                    j = need ? js : j;
+                }
+                return j;
+            };
+            const int lo = L.off[ax], hi = L.off[ax] + (int)L.shape[ax];
+            const int jlo = cross(lo);
+            const int jhi = cross(hi);
+            // increasing: inside on [jlo, jhi); decreasing: inside on [jhi, jlo)
             int en = inc ? jlo : jhi, ex = inc ? jhi : jlo;
             if (!(sp > 0.0f) && !(sp < 0.0f)) {            // constant index: inside always or never
-                const int v = axis_voxel(0, st, sp, P.size[ax], L.scale[ax]);
-                en = 0; ex = (lo <= v && v < hi) ? nsteps : 0;
+                en = 0; ex = (lo <= v0 && v0 < hi) ? nsteps : 0;
             }
             a = max(a, en); b = min(b, ex);
             // the slot constant changes only if the ROI really wraps on this axis (wave-uniform test);
             // otherwise encode "never": (n >= C) == inc must stay false
             if (L.wrap0[ax] + L.shape[ax] > L.ring[ax])
-                cr[ax] = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], (int)L.ring[ax] - L.addw[ax]);
+                cr[ax] = cross((int)L.ring[ax] - L.addw[ax]);
             else
                 cr[ax] = inc ? nsteps : 0;
         }
@@ -484,7 +546,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
 
-    bool found = false, finished = false;
+    bool found = false, finished = (P.dbg_nowait & 2) != 0;    // instruction-count experiments: prologue + epilogue only
     float local_max = 0.f, samp = 0.f;
     int hit_i = 0, since = 0;
     uint32_t steps = 0;
@@ -492,16 +554,25 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // LMIP state machine over one batch of U samples starting at iteration nb (raycast.wgsl:35-61).
     // `live`: this lane executes the batch; `tail`: some of its samples may lie beyond nsteps.
     // Skipped entirely while no lane can change state (nothing found yet, nothing >= threshold).
-    auto lmip_batch = [&](const float (&sv)[U], int nb, bool live, bool tail) {
-        float m = -1.0f;
+    typedef typename Texel<ESH>::type texel_t;
+    // "(f32)m >= threshold" on the raw texel: bytes compare as integers against ceil(threshold)
+    // (P.lmip_threshold_u8, 256 when no byte can reach it), f32 texels against the threshold itself
+    texel_t thr_raw;
+    if constexpr (ESH == 0) thr_raw = P.lmip_threshold_u8; else thr_raw = P.lmip_threshold;
+    auto lmip_batch = [&](const texel_t (&sv)[U], int nb, bool live, bool tail) {
+        // u8: 0 is neutral (a live lane always has one real sample); f32: -1 < every |s|
+        texel_t m;
+        if constexpr (ESH == 0) m = 0u; else m = -1.0f;
+        const texel_t neutral = m;
 #pragma unroll
-        for (int u = 0; u < U; ++u) m = fmaxf(m, (tail && (nb + u) >= nsteps) ? -1.0f : fabsf(sv[u]));
-        const bool need = live && (found || m >= P.lmip_threshold);
+        for (int u = 0; u < U; ++u) m = texel_max(m, (tail && (nb + u) >= nsteps) ? neutral : texel_abs(sv[u]));
+        const bool need = live && (found || m >= thr_raw);
         if (__builtin_amdgcn_ballot_w64(need) != 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool act = live && !finished && (!tail || (nb + u) < nsteps);
-                const float inten = fabsf(sv[u]);
+                const float val = texel_value(sv[u]);
+                const float inten = fabsf(val);
                 if (COUNT) steps += act ? 1u : 0u;
                 const bool was_found = found;
                 const bool first_hit = act && !was_found && inten >= P.lmip_threshold;     // :37
@@ -509,7 +580,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 since += tracking ? 1 : 0;                                                 // :47
                 const bool take = first_hit || (tracking && inten > local_max);            // :50
                 local_max = take ? inten : local_max;
-                samp = take ? sv[u] : samp;
+                samp = take ? val : samp;
                 hit_i = take ? (nb + u) : hit_i;
                 found = found || first_hit;
                 const bool brk = tracking && (since >= P.lmip_max_samples || inten < local_max * P.lmip_fall_off);  // :58
@@ -598,7 +669,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         if (run <= 0) {
             if (COUNT) ++c_general;
             // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
-            float s[U];
+            texel_t s[U];
             uint32_t off[U];
             const float basef = (float)n;
 #pragma unroll
@@ -628,9 +699,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
         if (first == NL) {
             // no LOD holds these voxels: every sample is 0 (sample_vol.wgsl:62)
-            float s[U];
+            texel_t s[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) s[u] = 0.0f;
+            for (int u = 0; u < U; ++u) s[u] = 0;
             for (; run > 0; --run) {
                 if (COUNT) ++c_zero;
                 const bool lv = alive && !finished && n < nsteps;
@@ -658,25 +729,30 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 // slab length: about 12 ring voxels of travel (coarser LODs advance less per iteration)
                 const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
                 const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
-                while (use_brick && (P.brick_lod_mask >> l & 1) && run >= slab / U && (L.ring[0] & 15u) == 0u) {
+                // packed 16-bit indices: the LOD's ROI must end below 2^15 on every axis
+                const bool brick_ok = (P.brick_lod_mask >> l & 1) && (L.ring[0] & 15u) == 0u &&
+                                      L.off[0] + (int)L.shape[0] < 32768 && L.off[1] + (int)L.shape[1] < 32768 &&
+                                      L.off[2] + (int)L.shape[2] < 32768;
+                while (use_brick && brick_ok && run >= slab / U) {
                     const bool live = alive && !finished && n < nsteps;
-                    const float fa = (float)n, fb = (float)min(n + slab - 1, nsteps - 1);   // last existing sample
-                    const int ax_ = (int)((R.start.x + fa * R.step.x) * ssx);
-                    const int ay_ = (int)((R.start.y + fa * R.step.y) * ssy);
-                    const int az_ = (int)((R.start.z + fa * R.step.z) * ssz);
-                    const int bx_ = (int)((R.start.x + fb * R.step.x) * ssx);
-                    const int by_ = (int)((R.start.y + fb * R.step.y) * ssy);
-                    const int bz_ = (int)((R.start.z + fb * R.step.z) * ssz);
-                    // exact box: (min, -max) per axis packed as two i16 -> three reductions (coords < 2^15)
-                    const short big = 0x7fff;
-                    short2_t px, py, pz;
-                    px.x = live ? (short)min(ax_, bx_) : big; px.y = live ? (short)(-max(ax_, bx_)) : big;
-                    py.x = live ? (short)min(ay_, by_) : big; py.y = live ? (short)(-max(ay_, by_)) : big;
-                    pz.x = live ? (short)min(az_, bz_) : big; pz.y = live ? (short)(-max(az_, bz_)) : big;
-                    px = wave_min2(px); py = wave_min2(py); pz = wave_min2(pz);
+                    // first and last existing sample of the slab, both at once with the packed chain
+                    const float2_t it = { (float)n, (float)min(n + slab - 1, nsteps - 1) };
+                    const float2_t ex = (it * R.step.x + R.start.x) * ssx;
+                    const float2_t ey = (it * R.step.y + R.start.y) * ssy;
+                    const float2_t ez = (it * R.step.z + R.start.z) * ssz;
+                    // exact box: per axis (min, ~max) as two i16 halves -> three packed-min reductions
+                    // (indices < 2^15, see brick_ok).  first | last << 16 is already (min, max) when the
+                    // ray travels up that axis; otherwise swap the halves.
+                    const uint32_t dead = 0x7fff7fffu;
+                    const uint32_t bx2 = live ? (halves_min_max(ex, R.step.x > 0.0f) ^ 0xffff0000u) : dead;
+                    const uint32_t by2 = live ? (halves_min_max(ey, R.step.y > 0.0f) ^ 0xffff0000u) : dead;
+                    const uint32_t bz2 = live ? (halves_min_max(ez, R.step.z > 0.0f) ^ 0xffff0000u) : dead;
+                    const short2_t px = wave_min2(__builtin_bit_cast(short2_t, bx2));
+                    const short2_t py = wave_min2(__builtin_bit_cast(short2_t, by2));
+                    const short2_t pz = wave_min2(__builtin_bit_cast(short2_t, bz2));
                     if (COUNT) ++c_slabs;
-                    if (px.x == big) { run = 0; break; }                 // no live lane left
-                    const int lx = px.x, hx = -(int)px.y, ly = py.x, hy = -(int)py.y, lz = pz.x, hz = -(int)pz.y;
+                    if (px.x == (short)0x7fff) { run = 0; break; }       // no live lane left
+                    const int lx = px.x, hx = ~(int)px.y, ly = py.x, hy = ~(int)py.y, lz = pz.x, hz = ~(int)pz.y;
                     // 16-voxel groups aligned in RING space, so a group never straddles the wrap
                     const int gx0 = lx - ((lx + L.addw[0]) & 15);
                     const int ngx = ((hx - gx0) >> 4) + 1;
@@ -713,18 +789,25 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
                     const uint32_t sh = (uint32_t)lgx + 4u;
                     const uint32_t bk = (uint32_t)wave_lds - (uint32_t)((((lz * ny + ly) << sh) + gx0));
-                    if (!P.dbg_nowait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(P.dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // address = y * S + z * (ny * S) + (x + bk),  S = 1 << sh: one dot2 on the packed (y, z)
+                    const uint32_t kyz = (1u << sh) | ((uint32_t)(ny << sh) << 16);
                     for (int k = 0; k < slab / U; ++k) {
-                        float s[U];
-                        const float basef = (float)n;
+                        texel_t s[U];
+                        float2_t iter = { (float)n, (float)n + 1.0f };
 #pragma unroll
                         for (int u = 0; u < U; u += 2) {
-                            const Idx2 v = voxel_pair(R, basef + (float)u, ssx, ssy, ssz);
-                            const uint32_t a0 = shl_add(mad24(v.z0, (uint32_t)ny, v.y0), sh, v.x0 + bk);
-                            const uint32_t a1 = shl_add(mad24(v.z1, (uint32_t)ny, v.y1), sh, v.x1 + bk);
-                            s[u] = (float)lds_all[a0];
-                            s[u + 1] = (float)lds_all[a1];
+                            const Idx2p v = voxel_pair_packed(R, iter, ssx, ssy, ssz);
+                            iter += 2.0f;
+                            const uint32_t a0 = dot2_u16(v.yz0, kyz, v.x0 + bk);
+                            const uint32_t a1 = dot2_u16(v.yz1, kyz, v.x1 + bk);
+                            s[u] = lds_all[a0];
+                            s[u + 1] = lds_all[a1];
                         }
+                        // pin the zero-extended bytes where they are loaded (ds_read_u8 already extends;
+                        // otherwise the extension is re-done with a v_and per sample in the consumer block)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) asm("" : "+v"(s[u]));
                         {
                             const bool lv = alive && !finished && n < nsteps;
                             // keep the no-tail case a compile-time constant (its per-sample tests fold away)
@@ -744,21 +827,22 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 const bool live = alive && !finished && n < nsteps;
                 if (__builtin_amdgcn_ballot_w64(live) == 0) break;
                 if (COUNT) ++c_direct;
-                float s[U];
+                texel_t s[U];
                 uint32_t off[U];
-                const float basef = (float)n;
+                float2_t iter = { (float)n, (float)n + 1.0f };
 #pragma unroll
                 for (int u = 0; u < U; u += 2) {
-                    const Idx2 v = voxel_pair(R, basef + (float)u, ssx, ssy, ssz);
+                    const Idx2 v = voxel_pair(R, iter, ssx, ssy, ssz);
+                    iter += 2.0f;
                     off[u] = mad24(mad24(v.z0, L.ring[1], v.y0), L.rx4, shl_add_c<ESH>(v.x0, Kc));
                     off[u + 1] = mad24(mad24(v.z1, L.ring[1], v.y1), L.rx4, shl_add_c<ESH>(v.x1, Kc));
                 }
+                // lanes that are not live fetch nothing; the LMIP update never looks at their samples
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = undefined_value<texel_t>();
                 if (live) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) s[u] = 0.0f;
                 }
                 if (__builtin_amdgcn_ballot_w64(live && n + U > nsteps) != 0) lmip_batch(s, n, live, true);
                 else lmip_batch(s, n, live, false);

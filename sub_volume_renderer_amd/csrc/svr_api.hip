@@ -409,6 +409,9 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     const svr_material& m = c->material;
     P.clim0 = m.clim[0]; P.clim1 = m.clim[1]; P.gamma = m.gamma; P.opacity = m.opacity;
     P.lmip_threshold = m.lmip_threshold; P.lmip_fall_off = m.lmip_fall_off;
+    P.lmip_threshold_u8 = 256u;                                    // NaN or > 255: no byte reaches it
+    if (m.lmip_threshold <= 0.0f) P.lmip_threshold_u8 = 0u;
+    else if (m.lmip_threshold <= 255.0f) P.lmip_threshold_u8 = (uint32_t)ceilf(m.lmip_threshold);
     P.lmip_max_samples = m.lmip_max_samples; P.fog_density = m.fog_density;
     for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
@@ -426,7 +429,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
     P.orient = (c->variant & 1024) ? 0 : 1;
-    P.dbg_nowait = (c->variant & 2048) ? 1 : 0;
+    P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };

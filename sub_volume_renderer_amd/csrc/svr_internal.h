@@ -40,6 +40,7 @@ struct MarchParams {
     // u_material
     float clim0, clim1, gamma, opacity;
     float lmip_threshold, lmip_fall_off;
+    uint32_t lmip_threshold_u8;    // smallest byte b with (float)b >= lmip_threshold (256: none)
     int32_t lmip_max_samples;
     float fog_density;
     float fog_color[3];
@@ -64,7 +65,7 @@ struct MarchParams {
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
-    int32_t dbg_nowait;            // timing experiment only (WRONG results): do not wait for the brick loads
+    int32_t dbg_nowait;            // experiments only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
     int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
     int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
     float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)
