@@ -201,6 +201,8 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
  * bits 11-12 instruction-count experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
+ * bits 13-15 block -> tile placement: 0 = chunks of 4x4 tiles dealt round-robin to the XCDs (default),
+ *            1 = one contiguous run of tiles per XCD, 2.. = chunks of 1x1, 4x2, 2x2, 8x4, 2x1, 4x4 tiles
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
  * bits 24-31 mask of LODs allowed to stage bricks (0 = default: all) */
 int  svr_set_variant(svr_ctx* ctx, int variant);

@@ -193,9 +193,10 @@ __device__ __forceinline__ void shade_and_store(const MarchParams& P, size_t o, 
     if (P.flags) P.flags[o] = cls;
 }
 
-// Block -> 16x16 pixel tile.  Workgroups are dealt round-robin to the 8 XCDs
-// (blockIdx b and b+8 share an XCD and its 4 MiB L2), so give each XCD a
-// contiguous run of tiles: neighbouring tiles sample neighbouring voxels.
+// Block -> 16x16 pixel tile when no placement table is given (MarchParams::tile_order, built by the
+// host: chunks of tiles dealt to the XCDs, see svr_api.hip).  Workgroups are dealt round-robin to the
+// 8 XCDs (blockIdx b and b+8 share an XCD and its 4 MiB L2); this fallback gives each XCD one
+// contiguous run of tiles: best L2 locality, but the runs (bands of the frame) differ in cost.
 // Placement only affects speed, never results.
 __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
     const int per = nblocks >> 3;            // full groups of 8
@@ -211,7 +212,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 template <int NL, bool COUNT>
 __global__ __launch_bounds__(256) void march_simple(const MarchParams P) {
     const int nblocks = P.tiles_x * P.tiles_y;
-    const int t = xcd_remap((int)blockIdx.x, nblocks);
+    const int t = P.tile_order ? (int)P.tile_order[blockIdx.x] : xcd_remap((int)blockIdx.x, nblocks);
     const int tile_x = t % P.tiles_x, tile_y = t / P.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // 4 waves = 2x2 sub-tiles of 8x8 pixels
@@ -451,7 +452,7 @@ template <int NL, int U, bool COUNT, int ESH>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[ESH == 0 ? 4 * kBrickBytes : 16];
     const int nblocks = P.tiles_x * P.tiles_y;
-    const int tb = xcd_remap((int)blockIdx.x, nblocks);
+    const int tb = P.tile_order ? (int)P.tile_order[blockIdx.x] : xcd_remap((int)blockIdx.x, nblocks);
     const int tile_x = tb % P.tiles_x, tile_y = tb / P.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // wave tile = (1 << lw) x (64 >> lw) pixels; a block is 2 x 2 wave tiles

@@ -130,6 +130,7 @@ int svr_destroy(svr_ctx* c) {
     }
     if (c->colors_dev) (void)hipFree(c->colors_dev);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
+    for (auto& t : c->tile_orders) if (t.dev) (void)hipFree(t.dev);
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
     if (c->render_done) (void)hipEventDestroy(c->render_done);
     if (c->uploads_marker) (void)hipEventDestroy(c->uploads_marker);
@@ -387,6 +388,59 @@ int svr_read_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t sha
 // ---------------------------------------------------------------------------
 // the draw
 // ---------------------------------------------------------------------------
+// Block -> tile table.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own
+// L2, so (1) tiles that sample neighbouring voxels should share an XCD and (2) every XCD should get the
+// same amount of work.  A contiguous run of tiles per XCD (mode 1) is best for (1) but gives each XCD
+// one horizontal band of the frame, and the bands differ in cost; instead deal CHUNKS of cw x ch tiles
+// round-robin to the XCDs, so each XCD samples the whole frame.  Placement never affects results.
+static void build_tile_order(int tx, int ty, int cw, int ch, std::vector<uint32_t>& order) {
+    const int n = tx * ty;
+    std::vector<uint32_t> seq;
+    seq.reserve((size_t)n);
+    for (int cy = 0; cy < ty; cy += ch)
+        for (int cx = 0; cx < tx; cx += cw)
+            for (int y = cy; y < std::min(cy + ch, ty); ++y)
+                for (int x = cx; x < std::min(cx + cw, tx); ++x) seq.push_back((uint32_t)(y * tx + x));
+    std::vector<uint32_t> lists[8];
+    const int run = cw * ch;
+    for (int i = 0; i < n; ++i) lists[(i / run) % 8].push_back(seq[(size_t)i]);
+    // XCD k runs blocks k, k + 8, ...: exactly ceil((n - k) / 8) of them
+    std::vector<uint32_t> spare;
+    for (int k = 0; k < 8; ++k) {
+        const size_t need = (size_t)((n - k + 7) / 8);
+        while (lists[k].size() > need) { spare.push_back(lists[k].back()); lists[k].pop_back(); }
+    }
+    for (int k = 0; k < 8; ++k) {
+        const size_t need = n > k ? (size_t)((n - k + 7) / 8) : 0;
+        while (lists[k].size() < need) { lists[k].push_back(spare.back()); spare.pop_back(); }
+    }
+    order.assign((size_t)n, 0u);
+    for (int k = 0; k < 8; ++k)
+        for (size_t j = 0; j < lists[k].size(); ++j) order[8 * j + (size_t)k] = lists[k][j];
+}
+
+static int tile_order_for(svr_ctx* c, int tx, int ty, int mode, const uint32_t** out) {
+    *out = nullptr;
+    if (mode == 1 || tx * ty <= 0) return SVR_OK;             // in-kernel contiguous mapping
+    for (const auto& t : c->tile_orders)
+        if (t.tiles_x == tx && t.tiles_y == ty && t.mode == mode) { *out = t.dev; return SVR_OK; }
+    std::vector<uint32_t> order;
+    static const int kChunk[8][2] = { { 4, 4 }, { 0, 0 }, { 1, 1 }, { 4, 2 }, { 2, 2 }, { 8, 4 }, { 2, 1 }, { 4, 4 } };
+    build_tile_order(tx, ty, kChunk[mode][0], kChunk[mode][1], order);
+    DeviceGuard guard(c->device);
+    uint32_t* dev = nullptr;
+    SVR_HIP_TRY(hipMalloc((void**)&dev, order.size() * sizeof(uint32_t)));
+    SVR_HIP_TRY(hipMemcpy(dev, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (c->tile_orders.size() >= 64) {                        // bounded cache: drop the oldest table once idle
+        (void)hipDeviceSynchronize();
+        (void)hipFree(c->tile_orders.front().dev);
+        c->tile_orders.erase(c->tile_orders.begin());
+    }
+    c->tile_orders.push_back({ tx, ty, mode, dev });
+    *out = dev;
+    return SVR_OK;
+}
+
 static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, MarchParams& P) {
     SVR_REQUIRE(c && cam && fr && out && out->rgba, "svr_render: null argument");
     SVR_REQUIRE(c->material_set, "svr_render: svr_set_material has not been called");
@@ -439,6 +493,10 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     const int bw = 2 << lw, bh = 2 * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
+    {   // variant bits 13-15: block -> tile policy (0 default = 4x4-tile chunks dealt to the XCDs, 1 contiguous, 2.. other chunk shapes)
+        const int rc_order = tile_order_for(c, P.tiles_x, P.tiles_y, (c->variant >> 13) & 7, &P.tile_order);
+        if (rc_order) return rc_order;
+    }
     for (int l = 0; l < c->num_lods; ++l) {
         const LodStorage& L = c->lod[l];
         LodParams& Q = P.lod[l];

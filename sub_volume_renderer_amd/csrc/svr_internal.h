@@ -65,6 +65,7 @@ struct MarchParams {
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
+    const uint32_t* tile_order;    // blockIdx -> tile index (null: contiguous run of tiles per XCD)
     int32_t dbg_nowait;            // experiments only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
     int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
     int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
@@ -118,6 +119,9 @@ struct svr_ctx {
     hipEvent_t render_done;          // recorded after the last enqueued render
     std::atomic<bool> render_pending;
     uint32_t*  dbg_dev;              // 8 diagnostic counters (instrumented renders)
+    // block -> tile tables (one per frame tiling and policy; entries are never rewritten)
+    struct TileOrder { int tiles_x, tiles_y, mode; uint32_t* dev; };
+    std::vector<TileOrder> tile_orders;
     hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
     std::atomic<bool> marker_set;
 };

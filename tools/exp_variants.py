@@ -46,7 +46,8 @@ for camname in cams:
             cb, fb = vol.camera_block(cam), vol.frame_block(W, H, None)
             ob = N.Outputs(); ob.rgba = r.rgba.data_ptr(); ob.depth = r.depth.data_ptr(); ob.label = r.label.data_ptr(); ob.flags = r.flags.data_ptr()
             ms = C.c_float(0)
-            N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), 5, C.byref(ms)), "time")
+            for iters in (10, 10):      # first pass = warm-up (clocks, caches)
+                N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)), "time")
             print(f"{camname:5s} {mode:5s} variant={v:#06x} steps={steps/1e6:8.1f}M {ms.value:7.3f} ms {steps/ms.value/1e6:7.1f} Gsteps/s "
                   f"{4*steps/ms.value/1e6/8000*100:5.1f}% {same} census[gen,dir,brick,slabs,runs,zero,waves]={census[:7]}", flush=True)
     del scene, vol
