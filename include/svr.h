@@ -196,13 +196,14 @@ int  svr_clear_lod(svr_ctx* ctx, int lod);
 int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
                 const svr_outputs* out, void* stream);
 /* kernel variant selector for A/B measurement (results are identical for every value):
- * bits 0-3  kernel: 0 = default span march, 1 = straightforward one-load-per-step march
+ * bits 0-3  kernel: 0 = default span march (one wave per workgroup), 1 = straightforward one-load-per-step
+ *            march, 2 = span march with 2x2 waves per workgroup
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
  * bits 11-12 instruction-count experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
- * bits 13-15 block -> tile placement: 0 = chunks of 4x4 tiles dealt round-robin to the XCDs (default),
- *            1 = one contiguous run of tiles per XCD, 2.. = chunks of 1x1, 4x2, 2x2, 8x4, 2x1, 4x4 tiles
+ * bits 13-15 block -> tile placement: 0 = 64x64-pixel chunks of tiles dealt round-robin to the XCDs (default),
+ *            1 = one contiguous run of tiles per XCD, 2.. = single tiles, 64x32, 32x32, 128x64, 32x16, 128x128 chunks
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
  * bits 24-31 mask of LODs allowed to stage bricks (0 = default: all) */
 int  svr_set_variant(svr_ctx* ctx, int variant);

@@ -450,14 +450,16 @@ constexpr int kBrickBytes = 8192;      // per wave; 4 waves per block -> 32 KiB 
 
 template <int NL, int U, bool COUNT, int ESH>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[ESH == 0 ? 4 * kBrickBytes : 16];
+    // dynamic LDS: kBrickBytes per wave of the block (u8 rings), see launch_nl
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     const int nblocks = P.tiles_x * P.tiles_y;
     const int tb = P.tile_order ? (int)P.tile_order[blockIdx.x] : xcd_remap((int)blockIdx.x, nblocks);
     const int tile_x = tb % P.tiles_x, tile_y = tb / P.tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // wave tile = (1 << lw) x (64 >> lw) pixels; a block is 2 x 2 wave tiles
-    const int lw = P.tile_log2w;
-    const int c0 = (tile_x * 2 + (wave & 1)) << lw, r0 = (tile_y * 2 + (wave >> 1)) << (6 - lw);
+    // wave tile = (1 << lw) x (64 >> lw) pixels; a block is one wave tile (wl = 0: a finished wave frees
+    // its slot at once) or 2 x 2 of them (wl = 1)
+    const int lw = P.tile_log2w, wl = P.block_waves_log2;
+    const int c0 = ((tile_x << wl) + (wave & wl)) << lw, r0 = ((tile_y << wl) + (wave >> 1)) << (6 - lw);
     // Lane order inside the wave tile.  The L1 serves a gather one lane-quad at a time and merges the
     // four lanes only when they hit the same line, so consecutive lanes should be neighbours along the
     // volume's contiguous axis x.  On screen, x points towards its vanishing point (the clip-space image
@@ -885,12 +887,16 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
-    } else if (p.density_u8) {
-        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(256), 0, stream, p);
-        else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
-        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 2>), dim3(nblocks), dim3(256), 0, stream, p);
-        else         hipLaunchKernelGGL((march_span<NL, 8, false, 2>), dim3(nblocks), dim3(256), 0, stream, p);
+        const int threads = 64 << (2 * p.block_waves_log2);
+        const size_t lds = p.density_u8 ? (size_t)kBrickBytes * (threads / 64) : 0;
+        if (p.density_u8) {
+            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
+            else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
+        } else {
+            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 2>), dim3(nblocks), dim3(threads), lds, stream, p);
+            else         hipLaunchKernelGGL((march_span<NL, 8, false, 2>), dim3(nblocks), dim3(threads), lds, stream, p);
+        }
     }
     return hipGetLastError();
 }

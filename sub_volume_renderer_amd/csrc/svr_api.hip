@@ -419,14 +419,17 @@ static void build_tile_order(int tx, int ty, int cw, int ch, std::vector<uint32_
         for (size_t j = 0; j < lists[k].size(); ++j) order[8 * j + (size_t)k] = lists[k][j];
 }
 
-static int tile_order_for(svr_ctx* c, int tx, int ty, int mode, const uint32_t** out) {
+static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, int mode, const uint32_t** out) {
     *out = nullptr;
     if (mode == 1 || tx * ty <= 0) return SVR_OK;             // in-kernel contiguous mapping
+    // chunk size in pixels per policy
+    static const int kChunk[8][2] = { { 64, 64 }, { 0, 0 }, { 1, 1 }, { 64, 32 }, { 32, 32 }, { 128, 64 }, { 32, 16 }, { 128, 128 } };
+    const int cw = std::max(1, kChunk[mode][0] / tile_w), ch = std::max(1, kChunk[mode][1] / tile_h);
+    const int key = mode | cw << 8 | ch << 16;
     for (const auto& t : c->tile_orders)
-        if (t.tiles_x == tx && t.tiles_y == ty && t.mode == mode) { *out = t.dev; return SVR_OK; }
+        if (t.tiles_x == tx && t.tiles_y == ty && t.mode == key) { *out = t.dev; return SVR_OK; }
     std::vector<uint32_t> order;
-    static const int kChunk[8][2] = { { 4, 4 }, { 0, 0 }, { 1, 1 }, { 4, 2 }, { 2, 2 }, { 8, 4 }, { 2, 1 }, { 4, 4 } };
-    build_tile_order(tx, ty, kChunk[mode][0], kChunk[mode][1], order);
+    build_tile_order(tx, ty, cw, ch, order);
     DeviceGuard guard(c->device);
     uint32_t* dev = nullptr;
     SVR_HIP_TRY(hipMalloc((void**)&dev, order.size() * sizeof(uint32_t)));
@@ -436,7 +439,7 @@ static int tile_order_for(svr_ctx* c, int tx, int ty, int mode, const uint32_t**
         (void)hipFree(c->tile_orders.front().dev);
         c->tile_orders.erase(c->tile_orders.begin());
     }
-    c->tile_orders.push_back({ tx, ty, mode, dev });
+    c->tile_orders.push_back({ tx, ty, key, dev });
     *out = dev;
     return SVR_OK;
 }
@@ -491,10 +494,13 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         mat_vec4(cam->world, ex, wx);
         mat_vec4(P.pc, wx, P.xdir);
     }
-    const int bw = 2 << lw, bh = 2 * (64 >> lw);
+    // kernel kind 0: span march, one wave per block; 2: span march, 2 x 2 waves per block; 1: simple (2 x 2)
+    // (rings of 4 GiB or more fall back to the simple kernel's 64-bit addressing, see launch_nl)
+    P.block_waves_log2 = ((c->variant & 15) == 0 && c->density_all_bytes < ((size_t)1 << 32)) ? 0 : 1;
+    const int bw = (1 << P.block_waves_log2) << lw, bh = (1 << P.block_waves_log2) * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
-    {   // variant bits 13-15: block -> tile policy (0 default = 4x4-tile chunks dealt to the XCDs, 1 contiguous, 2.. other chunk shapes)
-        const int rc_order = tile_order_for(c, P.tiles_x, P.tiles_y, (c->variant >> 13) & 7, &P.tile_order);
+    {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)
+        const int rc_order = tile_order_for(c, P.tiles_x, P.tiles_y, bw, bh, (c->variant >> 13) & 7, &P.tile_order);
         if (rc_order) return rc_order;
     }
     for (int l = 0; l < c->num_lods; ++l) {
@@ -540,7 +546,7 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     // unless the caller switched streams), so the draw is ordered with the caller's other work on it
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
-    SVR_HIP_TRY(svr_launch_march(P, c->variant & 15, s));
+    SVR_HIP_TRY(svr_launch_march(P, (c->variant & 15) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->render_done, s));
     c->render_pending = true;
     return SVR_OK;
@@ -556,7 +562,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
     hipStream_t s = c->render_stream;
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
-    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, c->variant & 15, s));
+    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, (c->variant & 15) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
     SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
     float ms = 0.f;
