@@ -232,6 +232,11 @@ int  svr_lod_device_ptrs(svr_ctx* ctx, int lod, void** density, void** labels);
  * [0] general batches, [1] direct fast batches, [2] brick batches, [3] brick slabs, [4] runs,
  * [5] all-zero batches, [6] waves; batches are per wave, 8 iterations each */
 int  svr_debug_counters(svr_ctx* ctx, uint32_t out[8], int reset);
+/* diagnostics: shader-clock cycles of wave residency per kernel section, summed over the waves of the
+ * instrumented renders: [0] prologue (ray set-up, event search), [1] span refresh + run length, [2] general
+ * batches, [3] brick slab set-up + load issue, [4] wait for the brick loads, [5] brick batches, [6] direct
+ * batches, [7] epilogue (shading, stores); [8..15] finer splits used while tuning (see march_kernel.hip) */
+int  svr_debug_timers(svr_ctx* ctx, uint64_t out[16], int reset);
 
 /* timing helper: run `iters` back-to-back renders on the context's render
  * stream bracketed by HIP events on that same stream; returns the average

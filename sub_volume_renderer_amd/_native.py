@@ -123,6 +123,7 @@ SIGNATURES = {
     "svr_sync": (C.c_int, [C.c_void_p]),
     "svr_sync_uploads": (C.c_int, [C.c_void_p]),
     "svr_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+    "svr_debug_timers": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "svr_lod_device_ptrs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "svr_time_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),
                                   C.POINTER(Outputs), C.c_int, C.POINTER(C.c_float)]),

@@ -387,12 +387,6 @@ __device__ __forceinline__ Idx2p voxel_pair_packed(const Ray& R, float2_t iter, 
     asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r.yz1) : "v"(cz.y));
     return r;
 }
-// i32(v.x) | i32(v.y) << 16 with the halves ordered (smaller, larger): `up` says v.x <= v.y
-__device__ __forceinline__ uint32_t halves_min_max(float2_t v, bool up) {
-    uint32_t ab = (uint32_t)(int)v.x;
-    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(ab) : "v"(v.y));
-    return up ? ab : __builtin_amdgcn_alignbit(ab, ab, 16);
-}
 // a.lo * b.lo + a.hi * b.hi + c on 16-bit halves (one VALU op)
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -402,39 +396,56 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 // a register with no defined value and no instruction (lanes whose value is never looked at)
 template <typename T> __device__ __forceinline__ T undefined_value() { T v; asm volatile("" : "=v"(v)); return v; }
 
-// wave64 reduction of two packed 16-bit minima at once (v_pk_min_i16): returns (min lo, min hi)
-__device__ __forceinline__ short2_t wave_min2(short2_t v) {
-#define SVR_DPP_STEP2(ctrl, rmask)                                                                          \
-    {                                                                                                       \
-        const int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),  \
-                                                   ctrl, rmask, 0xF, false);                                \
-        v = __builtin_elementwise_min(v, __builtin_bit_cast(short2_t, t_));                                 \
-    }
-    SVR_DPP_STEP2(0xB1, 0xF)
-    SVR_DPP_STEP2(0x4E, 0xF)
-    SVR_DPP_STEP2(0x141, 0xF)
-    SVR_DPP_STEP2(0x140, 0xF)
-    SVR_DPP_STEP2(0x142, 0xA)
-    SVR_DPP_STEP2(0x143, 0xC)
-#undef SVR_DPP_STEP2
-    return __builtin_bit_cast(short2_t, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+// Six wave64 reductions at once: min of a, b, c and max of d, e, f over all lanes; every lane of row 3
+// (lane 63 is read) ends up with the results.  Written out with DPP-fused VOP2 ops and the six
+// independent chains interleaved, so the two wait states a DPP read needs after a VALU write of its
+// source are always covered by the other chains (the compiler emits mov + nop + mov_dpp + op per step).
+__device__ __forceinline__ void wave_min3_max3(int& a, int& b, int& c, int& d, int& e, int& f) {
+#define SVR_STEP6(ctrl)                              \
+    "v_min_i32_dpp %0, %0, %0 " ctrl "\n"            \
+    "v_min_i32_dpp %1, %1, %1 " ctrl "\n"            \
+    "v_min_i32_dpp %2, %2, %2 " ctrl "\n"            \
+    "v_max_i32_dpp %3, %3, %3 " ctrl "\n"            \
+    "v_max_i32_dpp %4, %4, %4 " ctrl "\n"            \
+    "v_max_i32_dpp %5, %5, %5 " ctrl "\n"
+    asm volatile("s_nop 1\n"
+                 SVR_STEP6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 SVR_STEP6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 SVR_STEP6("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 SVR_STEP6("row_mirror row_mask:0xf bank_mask:0xf")
+                 SVR_STEP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 SVR_STEP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef SVR_STEP6
+    a = __builtin_amdgcn_readlane(a, 63); b = __builtin_amdgcn_readlane(b, 63); c = __builtin_amdgcn_readlane(c, 63);
+    d = __builtin_amdgcn_readlane(d, 63); e = __builtin_amdgcn_readlane(e, 63); f = __builtin_amdgcn_readlane(f, 63);
 }
 
-// wave64 min / max of an int via DPP (no LDS traffic); result is wave-uniform
+// wave64 min / max of an int via DPP (no LDS traffic); result is wave-uniform.  DPP-fused VOP2 ops
+// (a DPP read needs two wait states after the VALU write of its source)
 template <bool MAX>
 __device__ __forceinline__ int wave_reduce(int v) {
-#define SVR_DPP_STEP(ctrl, rmask)                                                   \
-    {                                                                               \
-        const int t_ = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xF, false);  \
-        v = MAX ? max(v, t_) : min(v, t_);                                          \
-    }
-    SVR_DPP_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
-    SVR_DPP_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
-    SVR_DPP_STEP(0x141, 0xF)   // row_half_mirror
-    SVR_DPP_STEP(0x140, 0xF)   // row_mirror: every lane of a row now holds the row result
-    SVR_DPP_STEP(0x142, 0xA)   // row_bcast15 into rows 1 and 3
-    SVR_DPP_STEP(0x143, 0xC)   // row_bcast31 into rows 2 and 3
-#undef SVR_DPP_STEP
+#define SVR_STEP1(ctrl) "s_nop 1\n" "v_min_i32_dpp %0, %0, %0 " ctrl "\n"
+#define SVR_STEP1X(ctrl) "s_nop 1\n" "v_max_i32_dpp %0, %0, %0 " ctrl "\n"
+    if (MAX)
+        asm volatile(SVR_STEP1X("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1X("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1X("row_half_mirror row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1X("row_mirror row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1X("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     SVR_STEP1X("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     "s_nop 0" : "+v"(v));
+    else
+        asm volatile(SVR_STEP1("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1("row_half_mirror row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1("row_mirror row_mask:0xf bank_mask:0xf")
+                     SVR_STEP1("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                     SVR_STEP1("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     "s_nop 0" : "+v"(v));
+#undef SVR_STEP1
+#undef SVR_STEP1X
     return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     const int nblocks = P.tiles_x * P.tiles_y;
     const int tb = P.tile_order ? (int)P.tile_order[blockIdx.x] : xcd_remap((int)blockIdx.x, nblocks);
     const int tile_x = tb % P.tiles_x, tile_y = tb / P.tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // wave tile = (1 << lw) x (64 >> lw) pixels; a block is one wave tile (wl = 0: a finished wave frees
     // its slot at once) or 2 x 2 of them (wl = 1)
     const int lw = P.tile_log2w, wl = P.block_waves_log2;
@@ -482,6 +493,17 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     const size_t o = (size_t)r * (size_t)P.frame.out_w + (size_t)c;
     const int x = P.frame.x0 + c;
     const int y = P.frame.y0 + (r / P.frame.band_h) * P.frame.band_pitch + (r % P.frame.band_h);
+
+    // instrumented build: shader-clock cycles per section (svr_debug_timers), wave-uniform
+    unsigned long long t_acc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long t_last = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](int k) {
+        if (COUNT) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_acc[k] += t - t_last;
+            t_last = t;
+        }
+    };
 
     Ray R;
     R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
@@ -623,6 +645,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // diagnostics of the instrumented build (COUNT): wave-level batch census
     int c_general = 0, c_direct = 0, c_brick = 0, c_slabs = 0, c_runs = 0, c_zero = 0;
     int n = 0;                                       // wave-uniform: every ray starts at iteration 0
+    lap(0);
     while (true) {
         const bool alive = !finished && n < nsteps;
         const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
@@ -668,6 +691,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         if (!alive) lane_run = 0x3fffffff;
         int run = wave_reduce<false>(lane_run);
         if (COUNT) ++c_runs;
+        lap(1);
 
         if (run <= 0) {
             if (COUNT) ++c_general;
@@ -697,6 +721,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
             lmip_batch(s, n, alive, true);
             n += U;
+            lap(2);
             continue;
         }
 
@@ -733,6 +758,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
                 const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
                 // packed 16-bit indices: the LOD's ROI must end below 2^15 on every axis
+                // packed (y, z) brick addresses: the LOD's ROI must end below 2^15 on every axis
                 const bool brick_ok = (P.brick_lod_mask >> l & 1) && (L.ring[0] & 15u) == 0u &&
                                       L.off[0] + (int)L.shape[0] < 32768 && L.off[1] + (int)L.shape[1] < 32768 &&
                                       L.off[2] + (int)L.shape[2] < 32768;
@@ -743,19 +769,15 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const float2_t ex = (it * R.step.x + R.start.x) * ssx;
                     const float2_t ey = (it * R.step.y + R.start.y) * ssy;
                     const float2_t ez = (it * R.step.z + R.start.z) * ssz;
-                    // exact box: per axis (min, ~max) as two i16 halves -> three packed-min reductions
-                    // (indices < 2^15, see brick_ok).  first | last << 16 is already (min, max) when the
-                    // ray travels up that axis; otherwise swap the halves.
-                    const uint32_t dead = 0x7fff7fffu;
-                    const uint32_t bx2 = live ? (halves_min_max(ex, R.step.x > 0.0f) ^ 0xffff0000u) : dead;
-                    const uint32_t by2 = live ? (halves_min_max(ey, R.step.y > 0.0f) ^ 0xffff0000u) : dead;
-                    const uint32_t bz2 = live ? (halves_min_max(ez, R.step.z > 0.0f) ^ 0xffff0000u) : dead;
-                    const short2_t px = wave_min2(__builtin_bit_cast(short2_t, bx2));
-                    const short2_t py = wave_min2(__builtin_bit_cast(short2_t, by2));
-                    const short2_t pz = wave_min2(__builtin_bit_cast(short2_t, bz2));
+                    // exact box of the wave's samples: min / max per axis over the live lanes
+                    const int big = 0x7fffffff;
+                    int lx = live ? min((int)ex.x, (int)ex.y) : big, hx = live ? max((int)ex.x, (int)ex.y) : -big;
+                    int ly = live ? min((int)ey.x, (int)ey.y) : big, hy = live ? max((int)ey.x, (int)ey.y) : -big;
+                    int lz = live ? min((int)ez.x, (int)ez.y) : big, hz = live ? max((int)ez.x, (int)ez.y) : -big;
+                    wave_min3_max3(lx, ly, lz, hx, hy, hz);
                     if (COUNT) ++c_slabs;
-                    if (px.x == (short)0x7fff) { run = 0; break; }       // no live lane left
-                    const int lx = px.x, hx = ~(int)px.y, ly = py.x, hy = ~(int)py.y, lz = pz.x, hz = ~(int)pz.y;
+                    lap(8);
+                    if (lx == big) { run = 0; break; }                   // no live lane left
                     // 16-voxel groups aligned in RING space, so a group never straddles the wrap
                     const int gx0 = lx - ((lx + L.addw[0]) & 15);
                     const int ngx = ((hx - gx0) >> 4) + 1;
@@ -773,6 +795,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     wx = min(wx, wx - L.ring[0]);
                     const uint32_t plane_bytes = (uint32_t)(ny << (lgx + 4));
                     const uint32_t zpitch = L.ring[1] * L.rx4;                       // bytes per ring z plane
+                    lap(9);
                     for (int yc = 0; yc < ny; yc += rows_per) {
                         const int yy = yc + ly_lane;
                         uint32_t wy = (uint32_t)(ly + yy + L.addw[1]);
@@ -792,7 +815,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
                     const uint32_t sh = (uint32_t)lgx + 4u;
                     const uint32_t bk = (uint32_t)wave_lds - (uint32_t)((((lz * ny + ly) << sh) + gx0));
+                    lap(3);
                     if (!(P.dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lap(4);
                     // address = y * S + z * (ny * S) + (x + bk),  S = 1 << sh: one dot2 on the packed (y, z)
                     const uint32_t kyz = (1u << sh) | ((uint32_t)(ny << sh) << 16);
                     for (int k = 0; k < slab / U; ++k) {
@@ -821,6 +846,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         if (COUNT) ++c_brick;
                     }
                     run -= slab / U;
+                    lap(5);
                     asm volatile("" ::: "memory");      // the next slab's loads must not overtake these LDS reads
                 }
             }
@@ -851,6 +877,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 else lmip_batch(s, n, live, false);
                 n += U;
             }
+            lap(6);
         }
     }
 
@@ -876,6 +903,14 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 #endif
         shade_and_store<NL>(*Pk, o, frag, h);
         if (COUNT && Pk->steps) Pk->steps[o] = h.steps;
+    }
+    if (COUNT && P.dbg) {
+        lap(7);
+        if (lane == 0) {
+            unsigned long long* t_out = reinterpret_cast<unsigned long long*>(P.dbg + 8);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(t_out + k, t_acc[k]);
+        }
     }
 }
 

@@ -473,8 +473,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
     P.num_lods = c->num_lods;
-    if (out->steps && !c->dbg_dev && hipMalloc((void**)&c->dbg_dev, 8 * sizeof(uint32_t)) == hipSuccess)
-        (void)hipMemset(c->dbg_dev, 0, 8 * sizeof(uint32_t));
+    if (out->steps && !c->dbg_dev && hipMalloc((void**)&c->dbg_dev, 40 * sizeof(uint32_t)) == hipSuccess)
+        (void)hipMemset(c->dbg_dev, 0, 40 * sizeof(uint32_t));      // 8 census counters + 16 u64 cycle sums
     P.dbg = out->steps ? c->dbg_dev : nullptr;
     P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
     // variant: bits 0-3 kernel kind (0 batched U=8, 1 simple, 2 batched U=4), bits 4-7 = 1 + log2 of the
@@ -617,6 +617,17 @@ int svr_debug_counters(svr_ctx* c, uint32_t out[8], int reset) {
     SVR_HIP_TRY(hipDeviceSynchronize());
     SVR_HIP_TRY(hipMemcpy(out, c->dbg_dev, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (reset) SVR_HIP_TRY(hipMemset(c->dbg_dev, 0, 8 * sizeof(uint32_t)));
+    return SVR_OK;
+}
+
+int svr_debug_timers(svr_ctx* c, uint64_t out[16], int reset) {
+    SVR_REQUIRE(c && out, "svr_debug_timers: null argument");
+    memset(out, 0, 16 * sizeof(uint64_t));
+    if (!c->dbg_dev) return SVR_OK;
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(hipDeviceSynchronize());
+    SVR_HIP_TRY(hipMemcpy(out, c->dbg_dev + 8, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) SVR_HIP_TRY(hipMemset(c->dbg_dev + 8, 0, 16 * sizeof(uint64_t)));
     return SVR_OK;
 }
 
