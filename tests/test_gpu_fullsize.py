@@ -108,7 +108,8 @@ def test_c2_tiles_stripes_and_variants_equal_full_frame(c2):
         assert torch.equal(r.rgba[keep], ref["rgba"][[rows[q] for q in keep]])
         assert torch.equal(r.label[keep], ref["label"][[rows[q] for q in keep]])
     # every kernel variant gives the same frame, bit for bit
-    for variant in (0x100, 0x200, 0x001, 0x250):
+    # (bricks never / always, simple march, tile shape, 2x2-wave workgroups, placement policies)
+    for variant in (0x100, 0x200, 0x001, 0x250, 0x002, 0x2000, 0x4000, 0xA202):
         N.check(N.lib().svr_set_variant(vol.prepare(), variant), "variant")
         r = vol.render(cam, W, H, count_steps=True)
         torch.cuda.synchronize()
