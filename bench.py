@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--camera", choices=["K1", "K2"], default="K1")
     ap.add_argument("--band-h", type=int, default=16)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="frames kept in flight on separate HIP streams (1: strictly one after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
@@ -142,35 +144,44 @@ def main():
                             frags=int((r.flags != 0).sum().item()))
     vol._out_cache = {}
 
-    # ---- outputs for the timed loop
-    out = vol._outputs(region.out_h, region.out_w, False)
-    outs = [out]
-    if world > 1:
+    # ---- outputs for the timed loop.  Successive frames are independent (camera poses are known ahead
+    # in a fly-through), so `in_flight` frames are kept in flight: frame k runs on stream k % in_flight
+    # with its own band buffer; on N > 1 each stream carries render -> RCCL gather -> un-tile of its
+    # frames, so frame k's collective and its tail of long rays overlap frame k+1's march.
+    F = max(1, args.in_flight)
+    vol._out_cache = {}
+    outs = []
+    for _ in range(F):
+        outs.append(vol._outputs(region.out_h, region.out_w, False))
         vol._out_cache = {}
-        outs.append(vol._outputs(region.out_h, region.out_w, False))        # double-buffered band outputs
-        out = outs[0]
+    out = outs[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [torch.cuda.current_stream(dev)]
     last_frame = [None]
     frame_no = [0]
+    pipelined = world > 1
 
     def frame():
-        buf = outs[frame_no[0] % len(outs)]
+        slot = frame_no[0] % F
         frame_no[0] += 1
-        res = vol.render(cam, W, H, region=region, out=buf)
-        if world > 1:
-            if args.backend == "nccl":
-                # RCCL gather of this frame's RGBA bands, overlapped with the next frame's march;
-                # the previous frame is completed (wait + un-tile kernel) here
-                f = tiled.gather_pipelined(res.rgba, dst=0, volume=vol)
-            else:
-                f = tiled.gather(res.rgba.cpu(), dst=0)                     # rehearsal through host memory
-            if f is not None:
-                last_frame[0] = f
+        with torch.cuda.stream(streams[slot]):
+            if pipelined:
+                f = tiled.finish(slot, dst=0)               # frame k - F: wait for its gather, un-tile (rank 0)
+                if f is not None:
+                    last_frame[0] = f
+            res = vol.render(cam, W, H, region=region, out=outs[slot])
+            if pipelined and args.backend == "nccl":
+                tiled.gather_async(res.rgba, slot, dst=0, volume=vol)      # RCCL gather of this frame's RGBA bands
+            elif pipelined:
+                tiled.gather_async(res.rgba.cpu(), slot, dst=0)             # gloo rehearsal through host memory
 
     def drain():
-        if world > 1 and args.backend == "nccl":
-            f = tiled.flush(dst=0)
-            if f is not None:
-                last_frame[0] = f
+        if pipelined:
+            for k in range(frame_no[0] - F, frame_no[0]):                   # oldest first
+                if k >= 0:
+                    with torch.cuda.stream(streams[k % F]):
+                        f = tiled.finish(k % F, dst=0)
+                        if f is not None:
+                            last_frame[0] = f
 
     def timed(mode, steps, warmup):
         set_mode(mode == "full")
@@ -252,6 +263,7 @@ def main():
                 "rays_with_fragment": counts["full"]["frags"],
                 "parallelism": "single" if world == 1 else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
                 "kernel_variant": args.variant,
+                "frames_in_flight": F,
                 "ring_storage": vol._rings.density_storage,
             },
         }

@@ -60,44 +60,68 @@ class TiledFrame:
         dist.gather(local, None, dst=dst)
         return None
 
+    # ---- frames in flight: slot-wise asynchronous gathers ------------------------------------------
+    def gather_async(self, local, slot: int = 0, dst: int = 0, volume=None):
+        """Start the gather of one frame's bands into buffer set ``slot`` and return at once.  The
+        collective is ordered after the work already enqueued on the current stream (the render that
+        wrote ``local``).  ``local`` must stay untouched until :meth:`finish` of the same slot."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            self._slots()[slot] = ("local", local, volume)
+            return
+        if tuple(local.shape[:2]) != (self.rows_per_rank, self.width):
+            raise ValueError(f"band buffer has shape {tuple(local.shape)}, expected ({self.rows_per_rank}, {self.width}, C)")
+        slots = self._slots()
+        if slots.get(slot) is not None:
+            raise RuntimeError(f"slot {slot} still holds an unfinished gather")
+        if self.rank == dst:
+            bufs = self.__dict__.setdefault("_slot_bufs", {})
+            b = bufs.get(slot)
+            if b is None or b[0].shape[1:] != local.shape or b[0].dtype != local.dtype or b[0].device != local.device:
+                b = (torch.empty((self.world, *local.shape), dtype=local.dtype, device=local.device),
+                     torch.empty((self.height, self.width, *local.shape[2:]), dtype=local.dtype, device=local.device))
+                bufs[slot] = b
+            work = dist.gather(local, list(b[0].unbind(0)), dst=dst, async_op=True)
+        else:
+            work = dist.gather(local, None, dst=dst, async_op=True)
+        slots[slot] = (work, local, volume)
+
+    def finish(self, slot: int = 0, dst: int = 0):
+        """Complete the gather started in ``slot``: the current stream waits for that collective, then
+        the bands are un-tiled.  Returns the frame on ``dst`` (``None`` elsewhere or if the slot is idle)."""
+        slots = self._slots()
+        pending, slots[slot] = slots.get(slot), None
+        if pending is None:
+            return None
+        work, local, volume = pending
+        if isinstance(work, str):                     # world == 1
+            return local
+        work.wait()                                   # the current stream waits for that collective only
+        if self.rank != dst:
+            return None
+        gathered, out = self._slot_bufs[slot]
+        return self.untile(gathered, out, volume)
+
+    def _slots(self):
+        return self.__dict__.setdefault("_slot_pending", {})
+
     def gather_pipelined(self, local, dst: int = 0, volume=None):
         """Like :meth:`gather`, but frame k's collective runs beside frame k+1's render: the gather is
         started asynchronously into one of two buffer sets and finished (wait + un-tile) one call later.
         Returns the PREVIOUS frame on ``dst`` (``None`` on the first call and on other ranks).  The
         caller must render successive frames into alternating band buffers.  Call :meth:`flush` at the end."""
-        import torch
-        import torch.distributed as dist
-
         if self.world == 1:
             return local
         k = self._pipe_k = getattr(self, "_pipe_k", -1) + 1
-        slot = k & 1
-        if self.rank == dst:
-            if getattr(self, "_pipe_bufs", None) is None or self._pipe_bufs[0].shape[1:] != local.shape:
-                self._pipe_bufs = [torch.empty((self.world, *local.shape), dtype=local.dtype, device=local.device)
-                                   for _ in range(2)]
-                self._pipe_frames = [torch.empty((self.height, self.width, *local.shape[2:]), dtype=local.dtype,
-                                                 device=local.device) for _ in range(2)]
-            work = dist.gather(local, list(self._pipe_bufs[slot].unbind(0)), dst=dst, async_op=True)
-        else:
-            work = dist.gather(local, None, dst=dst, async_op=True)
-        prev = getattr(self, "_pipe_pending", None)
-        self._pipe_pending = (work, slot, volume)
-        return self._finish(prev, dst)
-
-    def _finish(self, pending, dst):
-        if pending is None:
-            return None
-        work, slot, volume = pending
-        work.wait()                                   # the current stream waits for that collective only
-        if self.rank != dst:
-            return None
-        return self.untile(self._pipe_bufs[slot], self._pipe_frames[slot], volume)
+        self.gather_async(local, slot=k & 1, dst=dst, volume=volume)
+        return self.finish(slot=(k - 1) & 1, dst=dst) if k > 0 else None
 
     def flush(self, dst: int = 0):
         """Finish the last pipelined gather; returns the last frame on ``dst``."""
-        pending, self._pipe_pending = getattr(self, "_pipe_pending", None), None
-        return self._finish(pending, dst)
+        k = getattr(self, "_pipe_k", -1)
+        return self.finish(slot=k & 1, dst=dst) if k >= 0 else None
 
     def untile(self, gathered, out, volume=None):
         """``gathered[rank, r]`` -> ``out[frame_row]``.  On the GPU this is the ``svr_untile_stripes``

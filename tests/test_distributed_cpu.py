@@ -105,3 +105,50 @@ def test_pipelined_gather_returns_previous_frame(tmp_path):
     yy, xx = np.meshgrid(np.arange(21), np.arange(24), indexing="ij")
     for i in range(1, 5):                                        # call i returns frame i-1; flush returns frame 3
         np.testing.assert_array_equal(got[f"f{i}"][..., 0], 1000.0 * (i - 1) + 24.0 * yy + xx)
+
+
+def _slots_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, H, bh, depth = 16, 13, 2, 2
+        tf = TiledFrame(W, H, rank, world, bh)
+        rows = tf.frame_rows_of(rank)
+        done = {}
+        bands = [torch.empty((tf.rows_per_rank, W, 1)) for _ in range(depth)]   # one band buffer per slot
+        for k in range(5):                     # bench.py's loop: finish frame k - depth, render k, start its gather
+            slot = k % depth
+            f = tf.finish(slot, dst=0)
+            if rank == 0 and k >= depth:
+                done[k - depth] = f.clone()
+            else:
+                assert f is None
+            band = bands[slot]
+            band.fill_(-1.0)
+            for r, y in enumerate(rows):
+                if y >= 0:
+                    band[r, :, 0] = 1000.0 * k + 16.0 * y + torch.arange(W, dtype=torch.float32)
+            tf.gather_async(band, slot, dst=0)
+            with pytest.raises(RuntimeError):
+                tf.gather_async(band, slot, dst=0)                 # the slot is busy until finish()
+        for k in (3, 4):                       # drain, oldest first
+            f = tf.finish(k % depth, dst=0)
+            if rank == 0:
+                done[k] = f.clone()
+        assert tf.finish(0) is None and tf.finish(1) is None
+        if rank == 0:
+            np.savez(out_path, **{f"f{k}": v.numpy() for k, v in done.items()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_frames_in_flight_slots(tmp_path):
+    """gather_async / finish: two gathers in flight in separate slots (the multi-GPU bench loop)."""
+    out = str(tmp_path / "slots.npz")
+    mp.spawn(_slots_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    yy, xx = np.meshgrid(np.arange(13), np.arange(16), indexing="ij")
+    for k in range(5):
+        np.testing.assert_array_equal(got[f"f{k}"][..., 0], 1000.0 * k + 16.0 * yy + xx)
