@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define SVR_MAX_LODS 8
-#define SVR_ABI_VERSION 2
+#define SVR_ABI_VERSION 3
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -125,6 +125,11 @@ typedef struct svr_outputs {
     uint8_t*  flags;               /* SVR_PIX_* */
     uint32_t* steps;               /* executed iterations of raycast.wgsl:29-62 per pixel
                                       (instrumented build of the kernel; NULL in production) */
+    uint64_t* pick;                /* out.pick of the `write_pick` shader variant (fs_main.wgsl:89-92): the 64 bits of
+                                      pygfx's rgba16uint pick target, component k = bits 16k..16k+15:
+                                      [0,20) wobject id, [20,34) u32(coord.x*16383), [34,48) .y, [48,62) .z, each
+                                      clipped to its width (pygfx `pick_pack`, restated); 0 where nothing was hit */
+    uint32_t  pick_id;             /* u_wobject.id */
 } svr_outputs;
 
 typedef struct svr_ctx svr_ctx;

@@ -71,6 +71,8 @@ def lib():
             C.POINTER(_Camera), C.POINTER(_Frame), C.c_int, C.POINTER(_OracleLod), C.POINTER(_Material),
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
         ]
+        _lib.svr_oracle_render_pick.restype = C.c_int
+        _lib.svr_oracle_render_pick.argtypes = _lib.svr_oracle_render.argtypes[:-1] + [C.c_void_p, C.c_uint32, C.c_int]
         _lib.svr_oracle_max_threads.restype = C.c_int
     return _lib
 
@@ -82,6 +84,7 @@ class OracleResult:
     label: np.ndarray    # u32 [h, w]
     flags: np.ndarray    # u8  [h, w]
     steps: np.ndarray    # u32 [h, w]
+    pick: np.ndarray = None   # u64 [h, w] (only when a pick id was given)
 
 
 def _mat(m):
@@ -95,7 +98,7 @@ DEFAULT_COLORS = [(0.0, 1.0, 1.0), (0.25, 1.0, 1.0), (0.5, 1.0, 1.0), (0.75, 1.0
 
 
 def render(rings, matrices, volume_dimensions_shader, material, width, height, region=None,
-           colorspace_srgb=True, nthreads=0) -> OracleResult:
+           colorspace_srgb=True, nthreads=0, pick_id=None) -> OracleResult:
     """``rings``: list of dicts(density=f32 [z,y,x], labels=u32, offset, shape, scale) in shader order."""
     m = dict(DEFAULT_MATERIAL)
     m.update(material)
@@ -138,9 +141,16 @@ def render(rings, matrices, volume_dimensions_shader, material, width, height, r
     h, w = fr.out_h, fr.out_w
     out = OracleResult(np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32),
                        np.zeros((h, w), np.uint32), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint32))
-    rc = lib().svr_oracle_render(C.byref(cam), C.byref(fr), len(rings), lods, C.byref(cm),
-                                 out.rgba.ctypes.data, out.depth.ctypes.data, out.label.ctypes.data,
-                                 out.flags.ctypes.data, out.steps.ctypes.data, int(nthreads))
+    if pick_id is None:
+        rc = lib().svr_oracle_render(C.byref(cam), C.byref(fr), len(rings), lods, C.byref(cm),
+                                     out.rgba.ctypes.data, out.depth.ctypes.data, out.label.ctypes.data,
+                                     out.flags.ctypes.data, out.steps.ctypes.data, int(nthreads))
+    else:
+        out.pick = np.zeros((h, w), np.uint64)
+        rc = lib().svr_oracle_render_pick(C.byref(cam), C.byref(fr), len(rings), lods, C.byref(cm),
+                                          out.rgba.ctypes.data, out.depth.ctypes.data, out.label.ctypes.data,
+                                          out.flags.ctypes.data, out.steps.ctypes.data, out.pick.ctypes.data,
+                                          int(pick_id), int(nthreads))
     if rc != 0:
         raise RuntimeError(f"svr_oracle_render failed: {rc}")
     return out
@@ -166,11 +176,11 @@ def rings_of(vol: ring_oracle.OracleSubVolume) -> list:
     return rings
 
 
-def render_spec(spec, region=None, nthreads=0, vol=None) -> OracleResult:
+def render_spec(spec, region=None, nthreads=0, vol=None, pick_id=None) -> OracleResult:
     vol = vol or oracle_volume(spec)
     return render(rings_of(vol), spec.matrices(), vol.volume_dimensions_shader, spec.material,
                   spec.width, spec.height, region=region if region is not None else spec.region,
-                  colorspace_srgb=(spec.colorspace == "srgb"), nthreads=nthreads)
+                  colorspace_srgb=(spec.colorspace == "srgb"), nthreads=nthreads, pick_id=pick_id)
 
 
 def render_scene(scene, nthreads=0) -> OracleResult:

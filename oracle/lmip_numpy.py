@@ -33,13 +33,13 @@ def _mm(a, b):
     return out
 
 
-def render(rings, matrices, volume_dimensions_shader, material, width, height, colorspace_srgb=True):
+def render(rings, matrices, volume_dimensions_shader, material, width, height, colorspace_srgb=True, pick_id=None):
     """Full-frame render.  ``rings`` as in ``oracle.lmip.render``.  Returns dict of arrays."""
     with np.errstate(all="ignore"):
-        return _render(rings, matrices, volume_dimensions_shader, material, width, height, colorspace_srgb)
+        return _render(rings, matrices, volume_dimensions_shader, material, width, height, colorspace_srgb, pick_id)
 
 
-def _render(rings, M, vdim, mat, W, H, srgb):
+def _render(rings, M, vdim, mat, W, H, srgb, pick_id=None):
     world = np.asarray(M["world"], f32)
     ndc_to_data = _mm(_mm(np.asarray(M["world_inv"], f32), np.asarray(M["cam_inv"], f32)), np.asarray(M["proj_inv"], f32))
     pc = _mm(np.asarray(M["proj"], f32), np.asarray(M["cam"], f32))
@@ -181,10 +181,21 @@ def _render(rings, M, vdim, mat, W, H, srgb):
         fc = [f32(x) for x in mat["fog_color"]]
         rgba[hit] = np.stack([fc[0] * omf + r * fog, fc[1] * omf + g * fog, fc[2] * omf + b * fog,
                               np.full_like(r, f32(mat["opacity"]))], axis=-1)
-    return dict(rgba=rgba, depth=depth, label=label, flags=flags, steps=steps)
+    out = dict(rgba=rgba, depth=depth, label=label, flags=flags, steps=steps)
+    if pick_id is not None:                                           # fs_main.wgsl:89-92, pygfx pick_pack restated
+        pick = np.zeros((H, W), np.uint64)
+        if len(hit[0]):
+            word = np.full(len(hit[0]), min(int(pick_id), 0xFFFFF), np.uint64)
+            for k, shift in enumerate((20, 34, 48)):
+                f = (hit_coord[k][hit] * f32(16383.0)).astype(np.float64)
+                u = np.where(f > 0, np.minimum(np.floor(np.nan_to_num(f, nan=0.0)), 16383.0), 0.0).astype(np.uint64)
+                word |= u << np.uint64(shift)
+            pick[hit] = word
+        out["pick"] = pick
+    return out
 
 
-def render_spec(spec):
+def render_spec(spec, pick_id=None):
     from . import lmip
 
     vol = lmip.oracle_volume(spec)
@@ -194,4 +205,4 @@ def render_spec(spec):
         m["colors"] = lmip.DEFAULT_COLORS
     m["colors"] = [(*c, 1.0) for c in m["colors"]]
     return render(lmip.rings_of(vol), spec.matrices(), vol.volume_dimensions_shader, m, spec.width, spec.height,
-                  colorspace_srgb=(spec.colorspace == "srgb"))
+                  colorspace_srgb=(spec.colorspace == "srgb"), pick_id=pick_id)

@@ -154,7 +154,7 @@ typedef struct {
 
 /* One pixel = one fs_main invocation (or none).  Returns the SVR_PIX_* class. */
 static int shade_pixel(const frame_ctx* F, int W, int H, int i, int j,
-                       float rgba[4], float* depth, uint32_t* label, uint32_t* steps) {
+                       float rgba[4], float* depth, uint32_t* label, uint32_t* steps, float hit_coord[3]) {
     const svr_camera* C = F->cam; const svr_material* M = F->mat;
     const v3 sizef = F->sizef;
     rgba[0] = rgba[1] = rgba[2] = rgba[3] = 0.0f; *depth = 0.0f; *label = 0u; *steps = 0u;
@@ -268,16 +268,45 @@ static int shade_pixel(const frame_ctx* F, int W, int H, int i, int j,
     rgba[2] = M->fog_color[2] * omf + rgb.z * fog;
     rgba[3] = M->opacity;                               /* :86 */
     *label = seg;
+    hit_coord[0] = local_max_coord.x; hit_coord[1] = local_max_coord.y; hit_coord[2] = local_max_coord.z;
     return SVR_PIX_HIT;
+}
+
+/* fs_main.wgsl:89-92 (`write_pick` variant): pick_pack(id, 20) + pick_pack(u32(coord.x * 16383.0), 14) + ... y, z.
+ * pygfx's pick_pack (std.wgsl, third party, restated from its published text) clips the value to `bits` bits and
+ * places it at the running bit offset of a 64-bit word stored as four 16-bit components; WGSL's u32(f32) clamps
+ * to the u32 range.  Parity unpinned (no pick fixture exists upstream). */
+static uint32_t pick_field(float c) {
+    const float f = c * 16383.0f;
+    uint32_t u = 0u;
+    if (f > 0.0f) u = f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f;
+    return u < 16383u ? u : 16383u;
+}
+static uint64_t pick_word(uint32_t id, const float c[3]) {
+    return (uint64_t)(id < 0xFFFFFu ? id : 0xFFFFFu) | ((uint64_t)pick_field(c[0]) << 20) |
+           ((uint64_t)pick_field(c[1]) << 34) | ((uint64_t)pick_field(c[2]) << 48);
 }
 
 /* Render the pixels selected by `frame` (same row mapping as svr_frame in
  * include/svr.h).  Output arrays are HOST pointers, out_h*out_w elements
  * (rgba x4); any but rgba may be NULL.  nthreads <= 0: OpenMP default. */
+int svr_oracle_render_pick(const svr_camera* cam, const svr_frame* fr,
+                           int num_lods, const svr_oracle_lod* lods, const svr_material* mat,
+                           float* rgba, float* depth, uint32_t* label, uint8_t* flags, uint32_t* steps,
+                           uint64_t* pick, uint32_t pick_id, int nthreads);
+
 int svr_oracle_render(const svr_camera* cam, const svr_frame* fr,
                       int num_lods, const svr_oracle_lod* lods, const svr_material* mat,
                       float* rgba, float* depth, uint32_t* label, uint8_t* flags, uint32_t* steps,
                       int nthreads) {
+    return svr_oracle_render_pick(cam, fr, num_lods, lods, mat, rgba, depth, label, flags, steps, NULL, 0u, nthreads);
+}
+
+/* same, plus the pick plane (NULL: not wanted) */
+int svr_oracle_render_pick(const svr_camera* cam, const svr_frame* fr,
+                           int num_lods, const svr_oracle_lod* lods, const svr_material* mat,
+                           float* rgba, float* depth, uint32_t* label, uint8_t* flags, uint32_t* steps,
+                           uint64_t* pick, uint32_t pick_id, int nthreads) {
     if (!cam || !fr || !lods || !mat || !rgba || num_lods < 1 || mat->color_count == 0) return -1;
     frame_ctx F;
     F.cam = cam; F.mat = mat; F.n = num_lods; F.lods = lods;
@@ -302,10 +331,11 @@ int svr_oracle_render(const svr_camera* cam, const svr_frame* fr,
         for (int c = 0; c < fr->out_w; ++c) {
             int x = fr->x0 + c;
             size_t o = (size_t)r * (size_t)fr->out_w + (size_t)c;
-            float px[4], d; uint32_t lab, st; int cls = SVR_PIX_DISCARD;
+            float px[4], d, hc[3] = { 0.0f, 0.0f, 0.0f }; uint32_t lab, st; int cls = SVR_PIX_DISCARD;
             px[0] = px[1] = px[2] = px[3] = 0.0f; d = 0.0f; lab = 0u; st = 0u;
             if (x >= 0 && x < fr->frame_w && y >= 0 && y < fr->frame_h)
-                cls = shade_pixel(&F, fr->frame_w, fr->frame_h, x, y, px, &d, &lab, &st);
+                cls = shade_pixel(&F, fr->frame_w, fr->frame_h, x, y, px, &d, &lab, &st, hc);
+            if (pick) pick[o] = cls == SVR_PIX_HIT ? pick_word(pick_id, hc) : 0ull;
             rgba[o * 4 + 0] = px[0]; rgba[o * 4 + 1] = px[1]; rgba[o * 4 + 2] = px[2]; rgba[o * 4 + 3] = px[3];
             if (depth) depth[o] = d;
             if (label) label[o] = lab;

@@ -90,6 +90,8 @@ class Outputs(C.Structure):
         ("label", C.c_void_p),
         ("flags", C.c_void_p),
         ("steps", C.c_void_p),
+        ("pick", C.c_void_p),
+        ("pick_id", C.c_uint32),
     ]
 
 

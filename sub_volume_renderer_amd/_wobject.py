@@ -59,6 +59,7 @@ class RenderResult:
     label: "object | None"    # torch i32 [h, w]      bit pattern of the u32 label (raycast.wgsl:81)
     flags: "object | None"    # torch u8  [h, w]      0 discard / 1 miss / 2 hit
     steps: "object | None"    # torch i32 [h, w]      executed march iterations (instrumented)
+    pick: "object | None" = None   # torch i64 [h, w]   bit pattern of the 64-bit pick word (fs_main.wgsl:89-92)
 
     def label_numpy(self) -> np.ndarray:
         return self.label.cpu().numpy().view(np.uint32)
@@ -138,6 +139,9 @@ class SubVolume(_HasWorld):
         self._volume_dimensions = np.zeros(3, np.float32)
         self.volume_dimensions = base_data.shape
         self._material_version_pushed = -1
+        # pygfx gives every world object a process-wide id (the shader packs its low 20 bits into the pick word)
+        SubVolume._next_id = getattr(SubVolume, "_next_id", 0) + 1
+        self.id = SubVolume._next_id
         self._out_cache = {}
         self._cam_cache = None
         self._frame_cache = {}
@@ -319,10 +323,10 @@ class SubVolume(_HasWorld):
         fb.band_pitch = int(r.band_pitch or r.out_h)
         return fb
 
-    def _outputs(self, h, w, want_steps):
+    def _outputs(self, h, w, want_steps, want_pick=False):
         import torch
 
-        key = (h, w, bool(want_steps))
+        key = (h, w, bool(want_steps), bool(want_pick))
         res = self._out_cache.get(key)
         if res is None:
             dev = torch.device("cuda", self._rings.device if self._rings.device is not None else torch.cuda.current_device())
@@ -332,6 +336,7 @@ class SubVolume(_HasWorld):
                 label=torch.empty((h, w), dtype=torch.int32, device=dev),
                 flags=torch.empty((h, w), dtype=torch.uint8, device=dev),
                 steps=torch.empty((h, w), dtype=torch.int32, device=dev) if want_steps else None,
+                pick=torch.empty((h, w), dtype=torch.int64, device=dev) if want_pick else None,
             )
             self._out_cache = {key: res}
         return res
@@ -347,7 +352,8 @@ class SubVolume(_HasWorld):
         return handle
 
     def render(self, camera, width: int, height: int, *, region: FrameRegion | None = None,
-               count_steps: bool = False, out: RenderResult | None = None, stream=None) -> RenderResult:
+               count_steps: bool = False, out: RenderResult | None = None, stream=None,
+               pick: bool = False) -> RenderResult:
         """Draw this volume as seen by ``camera`` into device tensors.
 
         Replaces ``renderer.render(scene, camera)`` for the (SubVolume,
@@ -359,8 +365,8 @@ class SubVolume(_HasWorld):
         handle = self.prepare()
         cb = self.camera_block(camera)
         fb = self.frame_block(width, height, region)
-        res = out or self._outputs(fb.out_h, fb.out_w, count_steps)
-        okey = (id(res), bool(count_steps))
+        res = out or self._outputs(fb.out_h, fb.out_w, count_steps, pick)
+        okey = (id(res), bool(count_steps), bool(pick))
         cached = self._ob_cache.get(okey)
         if cached is not None and cached[0] is res:
             ob = cached[1]
@@ -371,6 +377,8 @@ class SubVolume(_HasWorld):
             ob.label = res.label.data_ptr() if res.label is not None else None
             ob.flags = res.flags.data_ptr() if res.flags is not None else None
             ob.steps = res.steps.data_ptr() if (count_steps and res.steps is not None) else None
+            ob.pick = res.pick.data_ptr() if (pick and res.pick is not None) else None   # the `write_pick` shader variant
+            ob.pick_id = self.id & 0xFFFFFFFF
             if len(self._ob_cache) > 8:
                 self._ob_cache.clear()
             self._ob_cache[okey] = (res, ob)

@@ -74,6 +74,15 @@ __device__ __forceinline__ uint32_t sample_label(const MarchParams& P, float cx,
     return 0u;
 }
 
+// pick_pack(u32(c * 16383.0), 14): WGSL's u32() of an f32 clamps to the u32 range (NaN -> 0), pick_pack
+// clips to the field width (pygfx std.wgsl, restated)
+__device__ __forceinline__ uint32_t pick_field(float c) {
+    const float f = c * 16383.0f;
+    uint32_t u = 0u;
+    if (f > 0.0f) u = f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f;
+    return min(u, 16383u);
+}
+
 // hsv_selection.wgsl:7-41
 __device__ __forceinline__ f3 hsv_to_rgb(float h, float s, float v) {
     f3 r;
@@ -191,6 +200,14 @@ __device__ __forceinline__ void shade_and_store(const MarchParams& P, size_t o, 
     if (P.depth) P.depth[o] = depth;
     if (P.label) P.label[o] = label;
     if (P.flags) P.flags[o] = cls;
+    if (P.pick) {                                                         // fs_main.wgsl:89-92 (write_pick)
+        unsigned long long pk = 0ull;
+        if (cls == SVR_PIX_HIT)
+            pk = (unsigned long long)min(P.pick_id, 0xFFFFFu) |
+                 ((unsigned long long)pick_field(h.coord.x) << 20) | ((unsigned long long)pick_field(h.coord.y) << 34) |
+                 ((unsigned long long)pick_field(h.coord.z) << 48);
+        P.pick[o] = pk;
+    }
 }
 
 // Block -> 16x16 pixel tile when no placement table is given (MarchParams::tile_order, built by the

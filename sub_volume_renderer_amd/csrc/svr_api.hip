@@ -477,6 +477,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         (void)hipMemset(c->dbg_dev, 0, 40 * sizeof(uint32_t));      // 8 census counters + 16 u64 cycle sums
     P.dbg = out->steps ? c->dbg_dev : nullptr;
     P.rgba = out->rgba; P.depth = out->depth; P.label = out->label; P.flags = out->flags; P.steps = out->steps;
+    P.pick = reinterpret_cast<unsigned long long*>(out->pick); P.pick_id = out->pick_id;
     // variant: bits 0-3 kernel kind (0 batched U=8, 1 simple, 2 batched U=4), bits 4-7 = 1 + log2 of the
     // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
     int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;

@@ -54,6 +54,7 @@ struct MarchParams {
     uint32_t* label;
     uint8_t*  flags;
     uint32_t* steps;
+    unsigned long long* pick; uint32_t pick_id;
     uint32_t* dbg;                 // batch census of the instrumented build (8 counters) or NULL
     // all LOD density rings live in ONE allocation so a single buffer resource
     // (32-bit byte offsets, hardware range check) addresses every LOD

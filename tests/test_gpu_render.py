@@ -284,3 +284,29 @@ def test_tiledframe_untile_paths_equal_full_render(world, band_h):
     assert torch.equal(out_gpu, whole_rgba)
     out_cpu = tf0.untile(gathered.cpu(), torch.empty_like(whole_rgba).cpu())
     assert torch.equal(out_cpu, whole_rgba.cpu())
+
+
+@pytest.mark.parametrize("simple", [False, True], ids=["span", "simple"])
+def test_pick_plane_matches_oracle(simple):
+    """The `write_pick` variant of the fragment shader (fs_main.wgsl:89-92): 64-bit pick word per pixel,
+    bit for bit (integer packing of the hit coordinate, which is IEEE-exact on both sides)."""
+    import torch
+
+    from sub_volume_renderer_amd import _native as N
+
+    spec = testing.synthetic_spec(64, 160, 96, threshold=0.4)
+    scene = testing.build(spec)
+    vol = scene.volume
+    N.check(N.lib().svr_set_variant(vol.prepare(), 1 if simple else 0), "svr_set_variant")
+    res = vol.render(scene.camera, scene.width, scene.height, pick=True)
+    torch.cuda.synchronize()
+    ref = lmip.render_spec(spec, pick_id=vol.id)
+    got = res.pick.cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got, ref.pick)
+    hit = ref.flags == 2
+    assert hit.sum() > 100 and np.all(got[~hit] == 0)
+    assert np.all((got[hit] & np.uint64(0xFFFFF)) == np.uint64(vol.id))
+    # a render without the pick plane leaves the other planes unchanged
+    res2 = vol.render(scene.camera, scene.width, scene.height)
+    torch.cuda.synchronize()
+    assert torch.equal(res2.label, res.label) and torch.equal(res2.rgba, res.rgba)

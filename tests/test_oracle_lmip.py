@@ -113,3 +113,24 @@ def test_region_rendering_matches_full_frame():
             np.testing.assert_array_equal(r.label[row], full.label[y])
         else:
             assert np.all(r.flags[row] == 0)
+
+
+def test_pick_word_layout_and_restatements_agree():
+    """fs_main.wgsl:89-92 (`write_pick`): 20 bits of wobject id, then 14 bits each of u32(coord * 16383)
+    for x, y, z, at running bit offsets of a 64-bit word (pygfx pick_pack, restated; parity unpinned)."""
+    spec = make_golden.specs()["k1"]
+    a = lmip.render_spec(spec, nthreads=2, pick_id=0x12345)
+    b = lmip_numpy.render_spec(spec, pick_id=0x12345)
+    np.testing.assert_array_equal(a.pick, b["pick"])
+    hit = a.flags == 2
+    assert hit.sum() > 0 and np.all(a.pick[~hit] == 0)
+    w = a.pick[hit]
+    assert np.all((w & np.uint64(0xFFFFF)) == np.uint64(0x12345))
+    for shift in (20, 34, 48):
+        f = (w >> np.uint64(shift)) & np.uint64(0x3FFF)
+        assert f.max() <= 16383 and f.min() >= 0 and len(np.unique(f)) > 4      # coordinates vary over the frame
+    assert np.all((w >> np.uint64(62)) == 0)
+    # an id wider than 20 bits is clipped, as pick_pack clips every field to its width
+    c = lmip.render_spec(spec, nthreads=2, pick_id=0xFFFFFFF)
+    assert np.all((c.pick[hit] & np.uint64(0xFFFFF)) == np.uint64(0xFFFFF))
+    np.testing.assert_array_equal(c.pick[hit] >> np.uint64(20), w >> np.uint64(20))
