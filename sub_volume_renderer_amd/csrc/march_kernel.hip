@@ -322,8 +322,8 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
 
 // Byte offset (inside MarchParams::density_all) of the texel under data coord d for a
 // voxel KNOWN to lie in LOD L's ROI; general form with the explicit ring wrap.
-template <int ESH>
-__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodParams& L, float dx, float dy, float dz) {
+template <int ESH, typename LodT>
+__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, float dy, float dz) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -464,6 +464,41 @@ __device__ __forceinline__ int wave_reduce(int v) {
 #undef SVR_STEP1
 #undef SVR_STEP1X
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// The kernel's own argument block through a pointer the optimiser cannot see through: uniforms read this
+// way are loaded where they are used and die there, instead of occupying SGPRs for the whole march loop
+// (the SGPR file is what limits this kernel, not the VGPRs).  The pointer stays in the constant address
+// space, so a read at a wave-uniform index is one scalar load.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const MarchParams __attribute__((address_space(4)))* kparams_t;
+__device__ __forceinline__ kparams_t fresh_params(const MarchParams&) {
+    kparams_t p = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#else
+typedef const MarchParams* kparams_t;
+__device__ inline kparams_t fresh_params(const MarchParams& P) { return &P; }
+#endif
+
+// The uniforms of one LOD that the march loop needs (MarchParams::lod[l], read through fresh_params)
+struct LodK {
+    uint32_t ring[3];
+    float    scale[3];
+    int32_t  addw[3];
+    uint32_t rx4, base_bytes;
+    float    ss[3];
+    int32_t  slab;
+};
+__device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
+    LodK k;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        k.ring[a] = p->lod[l].ring[a]; k.scale[a] = p->lod[l].scale[a]; k.addw[a] = p->lod[l].addw[a]; k.ss[a] = p->lod[l].ss[a];
+    }
+    k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
+    return k;
 }
 
 // Per-ray event table of one LOD
@@ -670,6 +705,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
         // ---- span refresh for the lanes whose span has ended
         if (__builtin_amdgcn_ballot_w64(alive && n >= E) != 0) {
+            const kparams_t Pr = fresh_params(P);
             if (alive && n >= E) {
                 code = NL; E = nsteps; Kc = 0xFFFFFFFFu;
                 bool settled = false;
@@ -677,7 +713,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 for (int l = 0; l < NL; ++l) {
                     const bool in = !settled && n >= ev[l].a && n < ev[l].b;
                     if (in) {
-                        const LodParams& L = P.lod[l];
+                        const LodK L = load_lod(Pr, l);
                         code = l;
                         E = min(E, ev[l].b);
                         // wrap constants in force at iteration n, and when they change next
@@ -704,7 +740,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         // a span that ends at the ray end may finish with a partial batch: its samples beyond nsteps
         // are fetched from harmless (range-checked / LDS) addresses and masked in the LMIP update
         int lane_run = (code == first) ? ((E == nsteps ? E - n + U - 1 : E - n) / U) : 0;
-        if (first < NL && !P.lod_pow2[first < NL ? first : 0]) lane_run = alive ? 0 : lane_run;   // fused constant needs 2^-k scales
+        if (first < NL && !fresh_params(P)->lod_pow2[first < NL ? first : 0]) lane_run = alive ? 0 : lane_run;   // fused constant needs 2^-k scales
         if (!alive) lane_run = 0x3fffffff;
         int run = wave_reduce<false>(lane_run);
         if (COUNT) ++c_runs;
@@ -713,6 +749,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         if (run <= 0) {
             if (COUNT) ++c_general;
             // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
+            const kparams_t Pg = fresh_params(P);
             texel_t s[U];
             uint32_t off[U];
             const float basef = (float)n;
@@ -720,15 +757,15 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             for (int u = 0; u < U; ++u) {
                 off[u] = 0xFFFFFFFFu;
                 const float iter = basef + (float)u;
-                const float dx = (R.start.x + iter * R.step.x) * P.size[0];
-                const float dy = (R.start.y + iter * R.step.y) * P.size[1];
-                const float dz = (R.start.z + iter * R.step.z) * P.size[2];
+                const float dx = (R.start.x + iter * R.step.x) * Pg->size[0];
+                const float dy = (R.start.y + iter * R.step.y) * Pg->size[1];
+                const float dz = (R.start.z + iter * R.step.z) * Pg->size[2];
                 bool done = !alive || (n + u) >= nsteps;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
                     if (__builtin_amdgcn_ballot_w64(sel) != 0) {
-                        const uint32_t ofs = lod_offset_wrapped<ESH>(P.lod[l], dx, dy, dz);
+                        const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz);
                         off[u] = sel ? ofs : off[u];
                     }
                     done = done || sel;
@@ -758,28 +795,21 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             continue;
         }
 
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            if (first != l) continue;
-            const LodParams& L = P.lod[l];
+        {
+            // the LOD every live lane is on: its constants are read here, once per run
+            const LodK L = load_lod(fresh_params(P), first);
             // scale is 2^-k here, so (coord*size)*scale == coord*(size*scale) bit for bit (scaling by a
             // power of two commutes with rounding): one multiply per axis instead of two
-            const float ssx = P.size[0] * L.scale[0], ssy = P.size[1] * L.scale[1], ssz = P.size[2] * L.scale[2];
+            const float ssx = L.ss[0], ssy = L.ss[1], ssz = L.ss[2];      // size * scale, multiplied on the host
 
             // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a
             // slab (ic is monotone per axis: first and last sample bound the rest) is staged into LDS
             // with coalesced 16-byte loads; the slab is then gathered from LDS, not through the L1,
             // which serves gathers one lane-quad at a time.
             if (ESH == 0) {
-                // slab length: about 12 ring voxels of travel (coarser LODs advance less per iteration)
-                const float smax = fmaxf(L.scale[0], fmaxf(L.scale[1], L.scale[2]));
-                const int slab = smax > 0.75f ? kSlab : (smax > 0.375f ? 2 * kSlab : 4 * kSlab);
-                // packed 16-bit indices: the LOD's ROI must end below 2^15 on every axis
-                // packed (y, z) brick addresses: the LOD's ROI must end below 2^15 on every axis
-                const bool brick_ok = (P.brick_lod_mask >> l & 1) && (L.ring[0] & 15u) == 0u &&
-                                      L.off[0] + (int)L.shape[0] < 32768 && L.off[1] + (int)L.shape[1] < 32768 &&
-                                      L.off[2] + (int)L.shape[2] < 32768;
-                while (use_brick && brick_ok && run >= slab / U) {
+                // slab length (host: about 12 ring voxels of travel; 0 where this LOD cannot stage bricks)
+                const int slab = L.slab;
+                while (use_brick && slab > 0 && run >= slab / U) {
                     const bool live = alive && !finished && n < nsteps;
                     // first and last existing sample of the slab, both at once with the packed chain
                     const float2_t it = { (float)n, (float)min(n + slab - 1, nsteps - 1) };

@@ -489,6 +489,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.orient = (c->variant & 1024) ? 0 : 1;
     P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
+    const int brick_mask = P.brick_lod_mask;
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
         float wx[4];
@@ -531,6 +532,15 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         const uint32_t des = c->density_u8 ? 1u : 4u;
         Q.rx4 = Q.ring[0] * des;
         Q.base_bytes = (uint32_t)(c->lod_base_bytes[l] * des);
+        for (int a = 0; a < 3; ++a) Q.ss[a] = P.size[a] * Q.scale[a];          // one IEEE multiply, as the kernel did
+        {   // brick slabs (u8 rings): about 12 ring voxels of travel per slab (coarser LODs advance less per
+            // iteration); rows in 16-byte groups, indices below 2^15 for the packed (y, z) brick address
+            const float smax = fmaxf(Q.scale[0], fmaxf(Q.scale[1], Q.scale[2]));
+            const int slab = smax > 0.75f ? 16 : (smax > 0.375f ? 32 : 64);
+            bool ok = c->density_u8 && (Q.ring[0] & 15u) == 0u && (brick_mask >> l & 1);
+            for (int a = 0; a < 3; ++a) ok = ok && (long long)Q.off[a] + (long long)Q.shape[a] < 32768;
+            Q.slab = ok ? slab : 0;
+        }
     }
     P.density_all = c->density_all;
     P.density_all_bytes = c->density_all_bytes < ((size_t)1 << 32) ? (uint32_t)c->density_all_bytes : 0u;

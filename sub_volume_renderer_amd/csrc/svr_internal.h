@@ -28,6 +28,8 @@ struct LodParams {
     uint32_t base_bytes;       // byte offset of this LOD's density ring inside MarchParams::density_all
     int32_t  addw[3];          // wrap0 - off: ring slot = wrap(ic + addw)
     uint32_t rx4;              // row pitch of the density ring in bytes (ring[0] * element size)
+    float    ss[3];            // size * scale (the fused per-axis factor of the fast paths when scale = 2^-k)
+    int32_t  slab;             // brick slab length in iterations (0: this LOD never stages bricks)
 };
 
 struct MarchParams {
