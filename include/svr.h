@@ -227,6 +227,20 @@ int  svr_untile_stripes(svr_ctx* ctx, const void* gathered, void* frame_out,
  * src_dims (x, y, z) must be even; dst has half the extent per axis.  Enqueued on `stream`. */
 int  svr_pool2x(int device, const void* src, void* dst, const int32_t src_dims[3], int dtype, int mode, void* stream);
 
+/* ---- display side: blend one render "over" a vertical-gradient background (top row =
+ * bg_top), optional depth test (fragment passes if depth < inout_depth, then writes it), linear -> sRGB,
+ * 8 bits per channel.  Restates what pygfx does after the fragment shader (blending src_alpha /
+ * one_minus_src_alpha, depth_compare "<", sRGB canvas); the reference's own tests draw over
+ * gfx.Background(None, BackgroundMaterial(bottom, top)) (tests/conftest.py:17-22).  DEVICE pointers;
+ * depth / flags / inout_depth may be NULL (NULL flags: every pixel is a fragment).  Parity unpinned. */
+typedef struct svr_compose_params {
+    float   bg_bottom[4];
+    float   bg_top[4];
+    int32_t srgb_encode;           /* 1: encode rgb with the sRGB OETF before quantising */
+} svr_compose_params;
+int  svr_compose(svr_ctx* ctx, const float* rgba, const float* depth, const uint8_t* flags, int width, int height,
+                 const svr_compose_params* params, uint8_t* out_rgba8, float* inout_depth, void* stream);
+
 /* ---- sync */
 int  svr_sync(svr_ctx* ctx);                 /* both streams idle */
 int  svr_sync_uploads(svr_ctx* ctx);         /* upload stream idle */

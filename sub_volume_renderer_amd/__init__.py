@@ -8,6 +8,7 @@ device work raises if ``csrc/libsvr_hip.so`` has not been built.
 """
 
 from ._geometry import Coordinate, Roi
+from .compose import compose
 from ._material import SubVolumeMaterial
 from ._transform import AffineTransform, PerspectiveCamera
 from ._wobject import FrameRegion, RenderResult, SubVolume
@@ -25,4 +26,6 @@ __all__ = [
     "FrameRegion",
     "RenderResult",
     "subtract_rois",
+    # display-side output of a render (pygfx's job in the reference)
+    "compose",
 ]

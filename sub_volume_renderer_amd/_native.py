@@ -95,6 +95,10 @@ class Outputs(C.Structure):
     ]
 
 
+class ComposeParams(C.Structure):
+    _fields_ = [("bg_bottom", C.c_float * 4), ("bg_top", C.c_float * 4), ("srgb_encode", C.c_int32)]
+
+
 _I3 = C.c_int32 * 3
 _L3 = C.c_int64 * 3
 
@@ -122,6 +126,8 @@ SIGNATURES = {
     "svr_untile_stripes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "svr_pool2x": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, _I3, C.c_int, C.c_int, C.c_void_p]),
+    "svr_compose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                              C.POINTER(ComposeParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "svr_sync": (C.c_int, [C.c_void_p]),
     "svr_sync_uploads": (C.c_int, [C.c_void_p]),
     "svr_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),

@@ -605,6 +605,17 @@ int svr_pool2x(int device, const void* src, void* dst, const int32_t src_dims[3]
     return SVR_OK;
 }
 
+int svr_compose(svr_ctx* c, const float* rgba, const float* depth, const uint8_t* flags, int width, int height,
+                const svr_compose_params* params, uint8_t* out_rgba8, float* inout_depth, void* stream) {
+    SVR_REQUIRE(c && rgba && params && out_rgba8, "svr_compose: null argument");
+    SVR_REQUIRE(width >= 0 && height >= 0, "svr_compose: negative size");
+    SVR_REQUIRE(!inout_depth || depth, "svr_compose: a depth test needs the render's depth plane");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(svr_launch_compose(rgba, depth, flags, width, height, *params, out_rgba8, inout_depth,
+                                   static_cast<hipStream_t>(stream)));
+    return SVR_OK;
+}
+
 int svr_sync(svr_ctx* c) {
     SVR_REQUIRE(c, "svr_sync: null ctx");
     DeviceGuard guard(c->device);

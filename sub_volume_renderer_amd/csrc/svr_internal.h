@@ -143,6 +143,8 @@ void svr_set_error(const std::string& msg);
 
 // kernels (march_kernel.hip / ring_kernels.hip) ------------------------------
 hipError_t svr_launch_march(const MarchParams& p, int variant, hipStream_t stream);
+hipError_t svr_launch_compose(const float* rgba, const float* depth, const uint8_t* flags, int w, int h,
+                              const svr_compose_params& q, uint8_t* out_rgba8, float* zbuf, hipStream_t stream);
 
 struct ScatterArgs {
     const void* src_density; int density_dtype; int64_t dstride[3];   // bytes per x,y,z step
