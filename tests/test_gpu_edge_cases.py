@@ -1,0 +1,94 @@
+"""GPU parity on inputs that leave the fast paths: LOD scales that are not powers of two (general batches
+only), rings whose x extent is not a multiple of 16 (no bricks), anisotropic volumes, tiny and ragged frames,
+degenerate material values (the integer pre-check of the byte rings must agree with the f32 comparison)."""
+import numpy as np
+import pytest
+
+from oracle import lmip
+from sub_volume_renderer_amd import _native as N, testing
+
+from test_gpu_render import check
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_pairs(shapes, seed, smooth=True):
+    rng = np.random.default_rng(seed)
+    pairs = []
+    for shp in shapes:
+        zz, yy, xx = np.meshgrid(*[np.arange(s, dtype=np.float32) / s for s in shp], indexing="ij")
+        base = 110 + 90 * np.cos(7 * xx + 3 * yy) * np.cos(5 * zz - 2 * yy) if smooth else 0
+        d = np.clip(base + rng.integers(0, 40, shp), 0, 255).astype(np.uint8)
+        lab = rng.integers(0, 5000, shp).astype(np.uint32)
+        pairs.append((d, lab))
+    return pairs
+
+
+@pytest.mark.parametrize("variant", [0x000, 0x200, 0x001], ids=["auto", "brick", "simple"])
+def test_lod_scales_not_powers_of_two(variant):
+    """96 -> 48 -> 32 voxels: scale factors 1, 1/2, 1/3.  The 1/3 LOD cannot use the fused size*scale factor."""
+    pairs = _random_pairs([(96,) * 3, (48,) * 3, (32,) * 3], 1)
+    spec = testing.synthetic_spec(96, 150, 100, pairs=pairs, threshold=0.55,
+                                  chunk_shapes=[(8, 8, 16), (4, 4, 16), (4, 4, 8)],
+                                  ring_shapes=[(5, 5, 2), (8, 8, 2), (8, 8, 4)],
+                                  sizes=[(30, 30, 30), (60, 60, 60), (96, 96, 96)])
+    scene = testing.build(spec)
+    assert [tuple(np.round(b.scale_factor, 4)) for b in scene.volume.wrapping_buffers][2] == (0.3333, 0.3333, 0.3333)
+    N.check(N.lib().svr_set_variant(scene.volume.prepare(), variant), "svr_set_variant")
+    _, ref, rep = check(scene)
+    assert len(np.unique(ref.label[ref.flags == 2])) > 50
+
+
+@pytest.mark.parametrize("variant", [0x000, 0x200])
+def test_ring_rows_not_multiple_of_16_and_anisotropic_volume(variant):
+    """(a0, a1, a2) = (40, 60, 84) voxels, chunks of 12 along x: ring rows of 36 / 60 bytes, so no LOD can
+    stage 16-byte brick groups; every sample goes through the gather path, whatever the variant asks for."""
+    pairs = _random_pairs([(40, 60, 84), (20, 30, 42)], 2)
+    spec = testing.synthetic_spec(84, 140, 90, pairs=pairs, threshold=0.5,
+                                  chunk_shapes=[(5, 6, 12), (5, 6, 6)], ring_shapes=[(4, 5, 3), (4, 5, 7)],
+                                  sizes=[(15, 24, 24), (40, 60, 84)])
+    c = (41.5, 29.5, 19.5)                                     # shader xyz = (a2, a1, a0) centre
+    spec.centers = [(c, spec.centers[0][1])]
+    spec.cam_target = c
+    spec.cam_position = (c[0] - 120.0, c[1] + 55.0, c[2] + 70.0)
+    scene = testing.build(spec)
+    N.check(N.lib().svr_set_variant(scene.volume.prepare(), variant), "svr_set_variant")
+    check(scene)
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (7, 3), (13, 9), (65, 17)])
+def test_tiny_and_ragged_frames(wh):
+    spec = testing.synthetic_spec(64, wh[0], wh[1], threshold=0.45)
+    check(testing.build(spec), want_hits=False)
+
+
+@pytest.mark.parametrize("material", [
+    dict(lmip_threshold=0.0), dict(lmip_threshold=-3.0), dict(lmip_threshold=float("nan")),
+    dict(lmip_threshold=255.0), dict(lmip_threshold=255.5), dict(lmip_threshold=254.000001),
+    dict(lmip_threshold=100.0, lmip_max_samples=0), dict(lmip_threshold=100.0, lmip_max_samples=1),
+    dict(lmip_threshold=100.0, lmip_fall_off=1.5), dict(lmip_threshold=100.0, lmip_fall_off=0.0),
+    dict(lmip_threshold=140.0, gamma=2.2, clim=(20.0, 200.0), opacity=0.25, fog_density=3.0),
+], ids=lambda m: ",".join(f"{k}={v}" for k, v in m.items()))
+@pytest.mark.parametrize("storage", ["native", "float32"])
+def test_degenerate_material_values(material, storage):
+    spec = testing.synthetic_spec(64, 120, 80)
+    spec.material.update(material)
+    spec.ring_storage = storage
+    scene = testing.build(spec)
+    res, ref, rep = check(scene, want_hits=False)
+    t = material.get("lmip_threshold")
+    if t is not None and t <= 0:
+        assert rep["n_miss"] == 0 and rep["n_hit"] > 0          # the very first sample is "significant"
+    if t is not None and (t != t or t > 255):
+        assert rep["n_hit"] == 0
+
+
+def test_max_byte_value_reaches_threshold_255():
+    """A voxel of 255 must be found with lmip_threshold = 255.0 (byte compare against ceil(threshold))."""
+    d = np.zeros((32, 32, 32), np.uint8)
+    d[10:20, 10:20, 10:20] = 255
+    lab = np.full((32, 32, 32), 7, np.uint32)
+    spec = testing.synthetic_spec(32, 96, 64, pairs=[(d, lab)], chunk_shapes=[(8, 8, 16)], ring_shapes=[(4, 4, 2)])
+    spec.material.update(lmip_threshold=255.0)
+    _, ref, rep = check(testing.build(spec))
+    assert rep["n_hit"] > 50
