@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // together fall into many different lines per lane-quad (the L1 does one lookup per distinct line
     // of each quad).  Probe it: at one iteration, count how many lanes hit a line that no lower lane of
     // their quad hits; > kBrickQuadLines lookups per load -> stage bricks.  P.brick: 0 never, 1 probe, 2 always.
-    bool use_brick = false;
+    int brick_mode = 0;                              // wave-uniform: 0 gathers only, 1 brick slabs, 2 slabs of twice the plain length
     if (ESH == 0 && P.brick) {
         const float pf = (float)min(max(nsteps - 1, 0), 256);
         const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> 7;       // 128 voxels per line
@@ -690,7 +690,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const bool fresh = frag && (q == 0 || (key != k0 && (q == 1 || (key != k1 && (q == 2 || key != k2)))));
         const int lines = __builtin_popcountll(__builtin_amdgcn_ballot_w64(fresh));
         const int quads = __builtin_popcountll(__builtin_amdgcn_ballot_w64(frag && q == 0)) + 1;
-        use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;               // lookups per full wave-load
+        const bool use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;   // lookups per full wave-load
+        brick_mode = use_brick ? 1 + P.slab_long : 0;
     }
     const int wave_lds = wave * kBrickBytes;
 
@@ -808,8 +809,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // which serves gathers one lane-quad at a time.
             if (ESH == 0) {
                 // slab length (host: about 12 ring voxels of travel; 0 where this LOD cannot stage bricks)
-                const int slab = L.slab;
-                while (use_brick && slab > 0 && run >= slab / U) {
+                // (doubled while the host's hint holds: rays nearly parallel to x make flat boxes, and the
+                // staged bytes per sample fall with the slab length; first misfit: back to the plain length)
+                while (brick_mode && L.slab > 0 && run >= (L.slab << (brick_mode >> 1)) / U) {
+                    const int slab = L.slab << (brick_mode >> 1);
                     const bool live = alive && !finished && n < nsteps;
                     // first and last existing sample of the slab, both at once with the packed chain
                     const float2_t it = { (float)n, (float)min(n + slab - 1, nsteps - 1) };
@@ -831,7 +834,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const int lgx = ngx <= 1 ? 0 : (32 - __builtin_clz(ngx - 1));
                     const int ny = hy - ly + 1, nz = hz - lz + 1;
                     const int groups = (ny * nz) << lgx;
-                    if (ny >= 512 || groups * 16 > kBrickBytes) { use_brick = false; break; }   // does not fit: direct
+                    if (ny >= 512 || groups * 16 > kBrickBytes) {            // does not fit
+                        if (brick_mode == 2) { brick_mode = 1; continue; }    // retry at the plain slab length
+                        brick_mode = 0; break;                                // march direct from here on
+                    }
                     // One load instruction per (z plane, chunk of 64 >> lgx rows): a lane's source offset is
                     // a per-lane constant (its row y and 16-voxel group) plus a wave-uniform z term, so the
                     // loop body is one VALU add.  Lanes beyond the plane's rows are masked off (an LDS-DMA

@@ -482,7 +482,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
     int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;
     if (lw > 6) lw = 6;
-    if ((c->variant & 15) == 1) lw = 3;                       // the simple kernel is 8x8 only
+    if ((c->variant & 3) == 1) lw = 3;                        // the simple kernel is 8x8 only
     P.tile_log2w = lw;
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
@@ -490,6 +490,18 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     const int brick_mask = P.brick_lod_mask;
+    {   // Central view direction in data space: the image of the NDC segment (0,0,-1)..(0,0,1).  Rays
+        // nearly parallel to x (the rings' contiguous axis) make flat slab boxes: start with long slabs.
+        const float n0[4] = { 0.f, 0.f, -1.f, 1.f }, f0[4] = { 0.f, 0.f, 1.f, 1.f };
+        float a[4], b[4];
+        mat_vec4(P.ndc_to_data, n0, a);
+        mat_vec4(P.ndc_to_data, f0, b);
+        float d[3], len = 0.f;
+        for (int k = 0; k < 3; ++k) { d[k] = b[k] / b[3] - a[k] / a[3]; len += d[k] * d[k]; }
+        len = sqrtf(len);
+        const bool along_x = len > 0.f && fabsf(d[0]) >= 0.94f * len;              // within ~20 degrees of x
+        P.slab_long = (along_x && !(c->variant & 4)) ? 1 : 0;                       // variant bit 2: never
+    }
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
         float wx[4];
@@ -498,7 +510,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     // kernel kind 0: span march, one wave per block; 2: span march, 2 x 2 waves per block; 1: simple (2 x 2)
     // (rings of 4 GiB or more fall back to the simple kernel's 64-bit addressing, see launch_nl)
-    P.block_waves_log2 = ((c->variant & 15) == 0 && c->density_all_bytes < ((size_t)1 << 32)) ? 0 : 1;
+    P.block_waves_log2 = ((c->variant & 3) == 0 && c->density_all_bytes < ((size_t)1 << 32)) ? 0 : 1;
     const int bw = (1 << P.block_waves_log2) << lw, bh = (1 << P.block_waves_log2) * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)
@@ -557,7 +569,7 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     // unless the caller switched streams), so the draw is ordered with the caller's other work on it
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
-    SVR_HIP_TRY(svr_launch_march(P, (c->variant & 15) == 1 ? 1 : 0, s));
+    SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->render_done, s));
     c->render_pending = true;
     return SVR_OK;
@@ -573,7 +585,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
     hipStream_t s = c->render_stream;
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
-    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, (c->variant & 15) == 1 ? 1 : 0, s));
+    for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
     SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
     float ms = 0.f;
