@@ -1,19 +1,60 @@
 """``SubVolumeMaterial`` — the parameter block of the LMIP march.
 
-Mirror of the reference's ``SubVolumeMaterial(gfx.VolumeMipMaterial)``
-(``src/sub_volume/_material.py:5-159``): same constructor, defaults, property
-names, validation and exception types.  Where the reference keeps the values in
-a pygfx uniform buffer, this class keeps them in a small numpy record with the
-same field types (``_material.py:6-24``) and hands them to the device through
-``svr_set_material`` (include/svr.h) whenever they changed.
+Drop-in for the reference's ``SubVolumeMaterial(gfx.VolumeMipMaterial)``
+(``src/sub_volume/_material.py``): same constructor arguments and defaults, same property
+names, same exception types on bad values.  The reference stores the values in a pygfx
+uniform buffer; here they live in a plain dict of numpy values with the field types of that
+uniform block (``_material.py:6-24``: f4 / i4 / 3xf4 / u4 / n*4xf4) and reach the device
+through ``svr_set_material`` (include/svr.h) whenever ``_version`` moved.
+
+The scalar uniforms are declared once, as data descriptors (``_Scalar``); the three
+structured ones (``clim``, ``fog_color``, ``colors``) are properties with their own checks.
 """
 
 from __future__ import annotations
 
+import numbers
+
 import numpy as np
+
+# the hues pygfx-side code falls back to when no colours are given (_material.py:51-57)
+_DEFAULT_HUES = (0.0, 0.25, 0.5, 0.75)
+
+
+class _Scalar:
+    """One scalar uniform: converts on assignment to the uniform's storage type and bumps the
+    material's version so that the next draw re-sends the block."""
+
+    def __init__(self, storage, doc, lo=None, hi=None):
+        self.storage, self.lo, self.hi = storage, lo, hi
+        self.__doc__ = doc
+
+    def __set_name__(self, owner, name):
+        self.field = name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        value = obj._u[self.field]
+        return float(value) if self.lo is not None else value      # clamped fields read back as python floats
+
+    def __set__(self, obj, value):
+        number = int(value) if np.issubdtype(self.storage, np.integer) else float(value)
+        if self.lo is not None:
+            number = min(max(number, self.lo), self.hi)
+        obj._store(self.field, self.storage(number))
 
 
 class SubVolumeMaterial:
+    # inherited from pygfx's VolumeMipMaterial in the reference
+    gamma = _Scalar(np.float32, "Exponent applied to the contrast-limited value before colouring.", -np.inf, np.inf)
+    opacity = _Scalar(np.float32, "Alpha written for hit pixels (fs_main.wgsl:86), kept inside [0, 1].", 0.0, 1.0)
+    # the LMIP uniforms (_material.py:60-99)
+    lmip_threshold = _Scalar(np.float32, "The minimum intensity considered significant for the LMIP algorithm.")
+    lmip_fall_off = _Scalar(np.float32, "The fraction of the maximum intensity that is still considered significant.")
+    lmip_max_samples = _Scalar(np.int32, "How many samples are examined after the first significant one (i32 in the shader).")
+    fog_density = _Scalar(np.float32, "The density of the fog effect applied to the volume.")
+
     def __init__(
         self,
         lmip_threshold: float,
@@ -26,156 +67,69 @@ class SubVolumeMaterial:
         gamma: float = 1.0,
         opacity: float = 1.0,
     ):
-        # the fields of the reference's uniform block (_material.py:6-24) plus the
-        # inherited VolumeMipMaterial ones (clim, gamma, opacity)
-        self._u = {
-            "clim": np.zeros(2, np.float32),
-            "gamma": np.float32(1.0),
-            "opacity": np.float32(1.0),
-            "lmip_threshold": np.float32(0.0),
-            "lmip_fall_off": np.float32(0.0),
-            "lmip_max_samples": np.int32(0),
-            "fog_density": np.float32(0.0),
-            "fog_color": np.zeros(3, np.float32),
-            "color_count": np.uint32(0),
-            "colors": np.zeros((0, 4), np.float32),
-        }
+        self._u = {}
         self._version = 0
-        # the reference forces depth testing on (_material.py:39-45); kept as an attribute
-        self.depth_test = True
-        self.clim = clim
-        self.gamma = gamma
-        self.opacity = opacity
-        self.lmip_threshold = lmip_threshold
-        self.lmip_fall_off = lmip_fall_off
-        self.lmip_max_samples = lmip_max_samples
-        self.fog_density = fog_density
-        self.fog_color = fog_color
-        if colors is None:
-            # _material.py:51-57
-            colors = [
-                (0.0, 1.0, 1.0),
-                (0.25, 1.0, 1.0),
-                (0.5, 1.0, 1.0),
-                (0.75, 1.0, 1.0),
-            ]
-        self.colors = colors
+        self.depth_test = True          # the reference insists on depth testing (_material.py:39-45)
+        arguments = dict(clim=clim, gamma=gamma, opacity=opacity, lmip_threshold=lmip_threshold,
+                         lmip_fall_off=lmip_fall_off, lmip_max_samples=lmip_max_samples, fog_density=fog_density,
+                         fog_color=fog_color,
+                         colors=[(h, 1.0, 1.0) for h in _DEFAULT_HUES] if colors is None else colors)
+        for name, value in arguments.items():
+            setattr(self, name, value)
 
-    def _touch(self):
+    def _store(self, field, value):
+        self._u[field] = value
         self._version += 1
 
-    # -- inherited from pygfx VolumeMipMaterial ----------------------------
+    # -- clim (VolumeMipMaterial) ----------------------------------------------------------------
     @property
     def clim(self) -> tuple[float, float]:
         """The contrast limits applied before colouring (sampled_value_to_color)."""
-        c = self._u["clim"]
-        return float(c[0]), float(c[1])
+        lo, hi = self._u["clim"]
+        return float(lo), float(hi)
 
     @clim.setter
-    def clim(self, clim) -> None:
-        if not (isinstance(clim, (tuple, list)) and len(clim) == 2):
+    def clim(self, limits) -> None:
+        if not isinstance(limits, (tuple, list)) or len(limits) != 2:
             raise TypeError("Material.clim must be a 2-tuple")
-        self._u["clim"] = np.array((float(clim[0]), float(clim[1])), np.float32)
-        self._touch()
+        self._store("clim", np.asarray([float(v) for v in limits], np.float32))
 
-    @property
-    def gamma(self) -> float:
-        return float(self._u["gamma"])
-
-    @gamma.setter
-    def gamma(self, value: float) -> None:
-        self._u["gamma"] = np.float32(float(value))
-        self._touch()
-
-    @property
-    def opacity(self) -> float:
-        return float(self._u["opacity"])
-
-    @opacity.setter
-    def opacity(self, value: float) -> None:
-        self._u["opacity"] = np.float32(min(max(float(value), 0.0), 1.0))
-        self._touch()
-
-    # -- _material.py:60-89 --------------------------------------------------
-    @property
-    def lmip_threshold(self) -> float:
-        """The minimum intensity considered significant for the LMIP algorithm."""
-        return self._u["lmip_threshold"]
-
-    @lmip_threshold.setter
-    def lmip_threshold(self, value: float) -> None:
-        self._u["lmip_threshold"] = np.float32(float(value))
-        self._touch()
-
-    @property
-    def lmip_fall_off(self) -> float:
-        """The fraction of the maximum intensity that is still considered significant."""
-        return self._u["lmip_fall_off"]
-
-    @lmip_fall_off.setter
-    def lmip_fall_off(self, value: float) -> None:
-        self._u["lmip_fall_off"] = np.float32(float(value))
-        self._touch()
-
-    @property
-    def lmip_max_samples(self) -> int:
-        """The maximum number of samples to consider after detecting a significant intensity."""
-        return self._u["lmip_max_samples"]
-
-    @lmip_max_samples.setter
-    def lmip_max_samples(self, value: int) -> None:
-        self._u["lmip_max_samples"] = np.int32(int(value))
-        self._touch()
-
-    # -- _material.py:90-117 -------------------------------------------------
-    @property
-    def fog_density(self) -> float:
-        """The density of the fog effect applied to the volume."""
-        return self._u["fog_density"]
-
-    @fog_density.setter
-    def fog_density(self, value: float) -> None:
-        self._u["fog_density"] = np.float32(float(value))
-        self._touch()
-
+    # -- fog colour: three numbers in [0, 1], anything else is a ValueError (_material.py:100-117) --------
     @property
     def fog_color(self) -> tuple[float, float, float]:
         """The color of the fog effect applied to the volume."""
         return tuple(self._u["fog_color"])
 
     @fog_color.setter
-    def fog_color(self, fog_color: tuple[float, float, float]) -> None:
-        if len(fog_color) != 3:
-            raise ValueError("fog_color must be a tuple of three floats (r, g, b)")
-        if not all(isinstance(c, (int, float)) for c in fog_color):
-            raise ValueError("fog_color must contain only numeric values")
-        fog_color = np.array(fog_color, dtype=np.float32)
-        if np.any(fog_color < 0) or np.any(fog_color > 1):
-            raise ValueError("fog_color values must be in the range [0, 1]")
-        self._u["fog_color"] = fog_color
-        self._touch()
+    def fog_color(self, rgb) -> None:
+        components = list(rgb)
+        if len(components) != 3:
+            raise ValueError(f"fog_color needs exactly three components (r, g, b), got {len(components)}")
+        for c in components:
+            if not isinstance(c, numbers.Real):
+                raise ValueError(f"fog_color components must be numbers, not {type(c).__name__}")
+        packed = np.asarray(components, np.float32)
+        if packed.min() < 0.0 or packed.max() > 1.0:
+            raise ValueError("fog_color components must lie in [0, 1]")
+        self._store("fog_color", packed)
 
-    # -- _material.py:119-159 ------------------------------------------------
+    # -- label hues: list of (h, s, v); stored vec4-padded like the reference's n*4xf4 array (:119-159) ---
     @property
-    def _color_count(self) -> int:
-        return self._u["color_count"]
+    def _color_count(self):
+        return np.uint32(len(self._u["colors"]))
 
     @property
     def colors(self) -> list[tuple[float, float, float]]:
-        """The list of HSV colors used for rendering labels (vec4-padded like the reference)."""
-        return [tuple(float(f) for f in row) for row in self._u["colors"]]
+        """The list of HSV colors used for rendering labels (each padded to four components)."""
+        return [tuple(map(float, row)) for row in self._u["colors"]]
 
     @colors.setter
-    def colors(self, colors: list[tuple[float, float, float]]):
-        if not isinstance(colors, (tuple, list)):
+    def colors(self, hsv_list) -> None:
+        if not isinstance(hsv_list, (list, tuple)):
             raise TypeError("Colors must be a list.")
-        colors2 = []
-        for color in colors:
-            if isinstance(color, (tuple, list)) and len(color) == 3:
-                # the reference pads every colour to a vec4 (_material.py:146-149)
-                colors2.append((*color, 1))
-            else:
-                raise TypeError(f"Each color must be an hsv tuple, not {color}")
-        self._u["colors"] = np.array(colors2, np.float32).reshape(len(colors2), 4)
-        self._u["color_count"] = np.uint32(len(colors2))
-        self._touch()
+        table = np.ones((len(hsv_list), 4), np.float32)               # fourth component: padding, always 1
+        for row, hsv in zip(table, hsv_list):
+            if not isinstance(hsv, (list, tuple)) or len(hsv) != 3:
+                raise TypeError(f"Each color must be an hsv tuple, not {hsv}")
+            row[:3] = hsv
+        self._store("colors", table)
