@@ -206,8 +206,7 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
- * bits 11-12, 3 timing experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march,
- *            3 = issue no brick loads at all
+ * bits 11-12 timing experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
  * bits 13-15 block -> tile placement: 0 = 64x64-pixel chunks of tiles dealt round-robin to the XCDs (default),
  *            1 = one contiguous run of tiles per XCD, 2.. = single tiles, 64x32, 32x32, 128x64, 32x16, 128x128 chunks
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)

@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         wy = min(wy, wy - L.ring[1]);
                         const uint32_t lane_src = mad24(wy, L.rx4, L.base_bytes + wx);
                         const uint32_t lds_chunk = (uint32_t)wave_lds + (uint32_t)(yc << (lgx + 4));
-                        if (yy < ny && !(P.dbg_nowait & 4)) {
+                        if (yy < ny) {
                             for (int zz = 0; zz < nz; ++zz) {
                                 uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);      // wave-uniform
                                 wz = min(wz, wz - L.ring[2]);

@@ -487,7 +487,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
     P.orient = (c->variant & 1024) ? 0 : 1;
-    P.dbg_nowait = ((c->variant >> 11) & 3) | ((c->variant & 8) ? 4 : 0);   // bit 11: no brick wait, bit 12: skip the march loop, bit 3: no brick loads
+    P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     const int brick_mask = P.brick_lod_mask;
     {   // Central view direction in data space: the image of the NDC segment (0,0,-1)..(0,0,1).  Rays
