@@ -159,12 +159,23 @@ def compare(res: RenderResult, ref) -> dict:
     attribute names).  Integer planes must match exactly; float planes are reported
     as max abs / max relative-or-abs error."""
     rgba = res.rgba.cpu().numpy()
+
+    def err(a, b):
+        """|a - b| where a NaN on both sides counts as equal (pow of a negative base: a clim above the
+        sample with a fractional gamma gives NaN in the shader too) and a NaN on one side as infinite."""
+        na, nb = np.isnan(a), np.isnan(b)
+        with np.errstate(invalid="ignore"):
+            d = np.abs(a - b)
+        d = np.where(na & nb, 0.0, d)
+        return np.where(na ^ nb, np.inf, d)
+
+    e_rgba = err(rgba, ref.rgba)
     out = {
         "flags_equal": bool(np.array_equal(res.flags.cpu().numpy(), ref.flags)),
         "labels_equal": bool(np.array_equal(res.label.cpu().numpy().view(np.uint32), ref.label)),
-        "rgba_max_abs": float(np.max(np.abs(rgba - ref.rgba))) if rgba.size else 0.0,
-        "rgba_max_rel": float(np.max(np.abs(rgba - ref.rgba) / np.maximum(1.0, np.abs(ref.rgba)))) if rgba.size else 0.0,
-        "depth_max_abs": float(np.max(np.abs(res.depth.cpu().numpy() - ref.depth))) if rgba.size else 0.0,
+        "rgba_max_abs": float(np.max(e_rgba)) if rgba.size else 0.0,
+        "rgba_max_rel": float(np.max(e_rgba / np.maximum(1.0, np.abs(np.nan_to_num(ref.rgba))))) if rgba.size else 0.0,
+        "depth_max_abs": float(np.max(err(res.depth.cpu().numpy(), ref.depth))) if rgba.size else 0.0,
         "n_hit": int(np.count_nonzero(ref.flags == 2)),
         "n_miss": int(np.count_nonzero(ref.flags == 1)),
         "n_discard": int(np.count_nonzero(ref.flags == 0)),
