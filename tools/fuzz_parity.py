@@ -2,7 +2,7 @@
 """Differential fuzzing of the HIP march against the CPU oracle: random volumes (1-4 LODs, random chunk
 and ring shapes, anisotropic, u8 or f32 rings), ring windows, cameras (outside / inside / grazing), materials,
 frame sizes, frame regions and kernel variants.  Integer planes must be identical, float planes within 1e-4.
-usage: fuzz_parity.py [cases] [first_seed]      (prints one line per failing case, then a summary)"""
+usage: fuzz_parity.py [cases] [first_seed] [brick]      (prints one line per failing case, then a summary)"""
 import os
 import sys
 
@@ -15,13 +15,21 @@ from sub_volume_renderer_amd import FrameRegion, _native as N, testing  # noqa: 
 VARIANTS = [0x000, 0x000, 0x200, 0x100, 0x002, 0x2000, 0x4000, 0x250, 0x230, 0x001, 0x204, 0xA202]
 
 
-def random_spec(seed):
+BRICK_VARIANTS = [0x200, 0x200, 0x204, 0x230, 0x250, 0xA202, 0x2200, 0x000]
+
+
+def random_spec(seed, brick=False):
+    """``brick=True`` biases the draw towards scenes that stage LDS bricks: 16-voxel chunks along x, byte
+    data, larger volumes and frames, variants that always stage."""
     rng = np.random.default_rng(seed)
     nl = int(rng.integers(1, 5))
     chunk0 = [int(rng.choice([4, 8])), int(rng.choice([4, 8])), int(rng.choice([8, 16, 12]))]
+    if brick:
+        chunk0[2] = 16 << max(0, nl - 2)                    # rows stay multiples of 16 bytes on every LOD
     nch = [int(rng.integers(3, 8)) for _ in range(3)]
     shape0 = [c * k * (1 << (nl - 1)) for c, k in zip(chunk0, nch)]
-    shape0 = [min(s, 96) // (c * (1 << (nl - 1))) * (c * (1 << (nl - 1))) or c * (1 << (nl - 1)) for s, c in zip(shape0, chunk0)]
+    cap = 160 if brick else 96
+    shape0 = [min(s, cap) // (c * (1 << (nl - 1))) * (c * (1 << (nl - 1))) or c * (1 << (nl - 1)) for s, c in zip(shape0, chunk0)]
     pairs, chunks, rings = [], [], []
     smooth = rng.random() < 0.7
     for l in range(nl):
@@ -31,7 +39,7 @@ def random_spec(seed):
         d = np.clip(base + rng.integers(0, 60, shp), 0, 255)
         if rng.random() < 0.25:
             d[rng.random(shp) < 0.5] = 0
-        d = d.astype(np.uint8) if rng.random() < 0.8 else (d / 255.0).astype(np.float32)
+        d = d.astype(np.uint8) if (brick or rng.random() < 0.8) else (d / 255.0).astype(np.float32)
         lab = rng.integers(0, int(rng.choice([3, 1000, 2**31])), shp).astype(np.uint32)
         pairs.append((d, lab))
         ch = tuple(max(1, c >> min(l, 1)) if rng.random() < 0.5 else c for c in chunk0)
@@ -42,7 +50,7 @@ def random_spec(seed):
         rings.append(tuple(int(rng.integers(2, max(3, s // c + 2))) for s, c in zip(shp, ch)))
     if any(p[0].dtype != pairs[0][0].dtype for p in pairs):
         pairs = [(p[0].astype(np.float32) if p[0].dtype != np.float32 else p[0], p[1]) for p in pairs]
-    W, H = int(rng.integers(9, 150)), int(rng.integers(7, 110))
+    W, H = (int(rng.integers(64, 260)), int(rng.integers(48, 180))) if brick else (int(rng.integers(9, 150)), int(rng.integers(7, 110)))
     size_xyz = np.array(shape0[::-1], float)
     centre = size_xyz * rng.uniform(0.2, 0.8, 3)
     mode = rng.integers(0, 3)
@@ -84,7 +92,7 @@ def random_spec(seed):
         spec.centers.append((tuple(np.array(spec.centers[0][0]) + rng.uniform(-9, 9, 3)), None))     # a second window move (ring wrap)
     if rng.random() < 0.2:
         spec.colorspace = "linear"
-    spec.ring_storage = "native" if rng.random() < 0.8 else "float32"
+    spec.ring_storage = "native" if (brick or rng.random() < 0.8) else "float32"
     region = None
     r = rng.random()
     if r < 0.2:
@@ -93,7 +101,7 @@ def random_spec(seed):
     elif r < 0.35:
         world = int(rng.integers(2, 5))
         region = FrameRegion.stripes(W, H, int(rng.integers(0, world)), world, int(rng.choice([1, 3, 8, 16])))
-    return spec, region, int(rng.choice(VARIANTS))
+    return spec, region, int(rng.choice(BRICK_VARIANTS if brick else VARIANTS))
 
 
 def main():
@@ -101,10 +109,12 @@ def main():
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    brick = len(sys.argv) > 3 and sys.argv[3] == "brick"
+    bricks = 0
     bad = skipped = hits = 0
     for seed in range(first, first + cases):
         try:
-            spec, region, variant = random_spec(seed)
+            spec, region, variant = random_spec(seed, brick)
             ovol = lmip.oracle_volume(spec)
         except Exception as e:          # a configuration the reference's own assertions reject
             skipped += 1
@@ -116,8 +126,13 @@ def main():
             bad += 1
             continue
         N.check(N.lib().svr_set_variant(scene.volume.prepare(), variant), "svr_set_variant")
+        import ctypes as C
+        dbg = (C.c_uint32 * 8)()
+        N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
         res = scene.volume.render(scene.camera, scene.width, scene.height, region=region, count_steps=True, pick=True)
         torch.cuda.synchronize()
+        N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
+        bricks += dbg[2] > 0
         ref = lmip.render_spec(spec, region=region, vol=ovol, pick_id=scene.volume.id)
         rep = testing.compare(res, ref)
         pick_ok = bool(np.array_equal(res.pick.cpu().numpy().view(np.uint64), ref.pick))
@@ -128,7 +143,8 @@ def main():
             bad += 1
             print(f"seed {seed}: MISMATCH variant={variant:#x} region={region} pick_ok={pick_ok} {rep}", flush=True)
         del scene
-    print(f"fuzz: {cases} cases from seed {first}: {bad} mismatching, {skipped} rejected by both, {hits} with hits", flush=True)
+    print(f"fuzz{' (brick-biased)' if brick else ''}: {cases} cases from seed {first}: {bad} mismatching, {skipped} rejected by both, "
+          f"{hits} with hits, {bricks} staged LDS bricks", flush=True)
     sys.exit(1 if bad else 0)
 
 
