@@ -55,6 +55,8 @@ def parse():
                     help="nccl = RCCL over xGMI (default); gloo: rehearsal of the N>1 path when several ranks must "
                          "share one GPU (bands are gathered through host memory; not a performance number)")
     ap.add_argument("--check", action="store_true", help="also compare the sampled rows with the oracle")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: run the N > 1 pipeline (bands, RCCL gather, un-tile) in a one-rank process group")
     return ap.parse_args()
 
 
@@ -98,8 +100,12 @@ def main():
     if args.backend == "gloo":
         local_rank = local_rank % max(1, ndev)           # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -124,7 +130,7 @@ def main():
     vol, cam = scene.volume, scene.camera
     N.check(N.lib().svr_set_variant(vol._rings.handle, args.variant), "svr_set_variant")
 
-    tiled = TiledFrame(W, H, rank, world, args.band_h)
+    tiled = TiledFrame(W, H, rank, world, args.band_h, force_collective=args.force_collective)
     region = tiled.region
     full_frame = FrameRegion.full(W, H)
     modes = [m for m in args.modes.split(",") if m]
@@ -158,7 +164,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [torch.cuda.current_stream(dev)]
     last_frame = [None]
     frame_no = [0]
-    pipelined = world > 1
+    pipelined = collective
 
     def frame():
         slot = frame_no[0] % F
@@ -188,7 +194,7 @@ def main():
         for _ in range(warmup):
             frame()
         drain()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -196,10 +202,10 @@ def main():
             frame()
         drain()                                          # the K-th frame's gather + un-tile are inside the timed region
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         dt = time.perf_counter() - t
-        if world > 1:
+        if collective:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -261,7 +267,7 @@ def main():
                             f"rings {spec.ring_shapes} chunks, {W}x{H}, camera {args.camera}, march_mode=full",
                 "ray_steps_per_frame": counts["full"]["steps"],
                 "rays_with_fragment": counts["full"]["frags"],
-                "parallelism": "single" if world == 1 else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
+                "parallelism": "single" if not collective else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
                 "kernel_variant": args.variant,
                 "frames_in_flight": F,
                 "ring_storage": vol._rings.density_storage,
@@ -350,7 +356,7 @@ def main():
             torch.cuda.synchronize()
             result["check"] = testing.compare(res, ref)
 
-    if rank == 0 and world > 1 and args.check:
+    if rank == 0 and collective and args.check:
         set_mode(True)
         frame_full = vol.render(cam, W, H, region=full_frame)
         torch.cuda.synchronize()
@@ -361,20 +367,20 @@ def main():
         got = last_frame[0]
         got = got.to(frame_full.rgba.device)
         bad = (got != frame_full.rgba).any(dim=-1)
-        result["check"] = {"gathered_frame_equals_single_gpu_render": bool(torch.equal(got, frame_full.rgba)),
+        result["check" if world > 1 else "check_gathered"] = {"gathered_frame_equals_single_gpu_render": bool(torch.equal(got, frame_full.rgba)),
                            "mismatched_pixels": int(bad.sum().item()),
                            "coloured_pixels_gathered": int((got[..., :3].abs().sum(-1) > 0).sum().item()),
                            "coloured_pixels_single": int((frame_full.rgba[..., :3].abs().sum(-1) > 0).sum().item()),
                            "alpha1_gathered": int((got[..., 3] == 1).sum().item()),
                            "alpha1_single": int((frame_full.rgba[..., 3] == 1).sum().item()),
                            "mismatched_rows": [int(v) for v in torch.nonzero(bad.any(dim=1)).flatten()[:12].tolist()]}
-    elif world > 1 and args.check:
+    elif collective and args.check:
         set_mode(True)
         frame()
         drain()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

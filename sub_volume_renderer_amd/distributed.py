@@ -22,13 +22,16 @@ from ._wobject import FrameRegion
 class TiledFrame:
     """Row-band decomposition of a ``width x height`` frame over ``world`` ranks."""
 
-    def __init__(self, width: int, height: int, rank: int, world: int, band_h: int = 16):
+    def __init__(self, width: int, height: int, rank: int, world: int, band_h: int = 16, force_collective: bool = False):
         if not (0 <= rank < world):
             raise ValueError("rank out of range")
         if band_h <= 0:
             raise ValueError("band_h must be positive")
         self.width, self.height, self.rank, self.world, self.band_h = width, height, rank, world, band_h
-        self.region = FrameRegion.stripes(width, height, rank, world, band_h) if world > 1 else FrameRegion.full(width, height)
+        # a world of one normally skips banding and the collective; `force_collective` keeps both (a
+        # one-rank RCCL group exercises the whole N > 1 code path on a single GPU)
+        self.collective = world > 1 or force_collective
+        self.region = FrameRegion.stripes(width, height, rank, world, band_h) if self.collective else FrameRegion.full(width, height)
         self.rows_per_rank = self.region.out_h
         self._gathered = None
         self._frame = None
@@ -47,7 +50,7 @@ class TiledFrame:
         import torch
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self.collective:
             return local
         if tuple(local.shape[:2]) != (self.rows_per_rank, self.width):
             raise ValueError(f"band buffer has shape {tuple(local.shape)}, expected ({self.rows_per_rank}, {self.width}, C)")
@@ -68,7 +71,7 @@ class TiledFrame:
         import torch
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self.collective:
             self._slots()[slot] = ("local", local, volume)
             return
         if tuple(local.shape[:2]) != (self.rows_per_rank, self.width):
@@ -96,7 +99,7 @@ class TiledFrame:
         if pending is None:
             return None
         work, local, volume = pending
-        if isinstance(work, str):                     # world == 1
+        if isinstance(work, str):                     # no collective: the local buffer is the frame
             return local
         work.wait()                                   # the current stream waits for that collective only
         if self.rank != dst:
@@ -112,7 +115,7 @@ class TiledFrame:
         started asynchronously into one of two buffer sets and finished (wait + un-tile) one call later.
         Returns the PREVIOUS frame on ``dst`` (``None`` on the first call and on other ranks).  The
         caller must render successive frames into alternating band buffers.  Call :meth:`flush` at the end."""
-        if self.world == 1:
+        if not self.collective:
             return local
         k = self._pipe_k = getattr(self, "_pipe_k", -1) + 1
         self.gather_async(local, slot=k & 1, dst=dst, volume=volume)
