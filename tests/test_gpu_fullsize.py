@@ -143,3 +143,25 @@ def test_c2_oracle_parity_on_sampled_rows(c2, mode):
     assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
     assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
     assert rep["total_steps"] > 30_000_000
+
+
+def test_one_rank_rccl_pipeline_equals_single_gpu_frame():
+    """bench.py's N > 1 pipeline on real RCCL in a one-rank process group (own process: the group and the
+    library state stay out of this one): row bands, asynchronous gather of device tensors on four streams,
+    un-tile kernel; the gathered frame must equal the single-GPU render."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--check",
+                          "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--modes", "full",
+                          "--volume-n", "256", "--width", "640", "--height", "360"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["config"]["parallelism"].startswith("frame row-bands x1")
+    assert res["check_gathered"]["gathered_frame_equals_single_gpu_render"] is True
+    assert res["check_gathered"]["alpha1_gathered"] > 1000
