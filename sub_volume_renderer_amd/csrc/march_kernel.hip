@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // together fall into many different lines per lane-quad (the L1 does one lookup per distinct line
     // of each quad).  Probe it: at one iteration, count how many lanes hit a line that no lower lane of
     // their quad hits; > kBrickQuadLines lookups per load -> stage bricks.  P.brick: 0 never, 1 probe, 2 always.
-    int brick_mode = 0;                              // wave-uniform: 0 gathers only, 1 brick slabs, 2 slabs of twice the plain length
+    int brick_mode = 0;                              // wave-uniform: 0 gathers only, k > 0 brick slabs of 2^(k-1) times the plain length
     if (ESH == 0 && P.brick) {
         const float pf = (float)min(max(nsteps - 1, 0), 256);
         const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> 7;       // 128 voxels per line
@@ -809,10 +809,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // which serves gathers one lane-quad at a time.
             if (ESH == 0) {
                 // slab length (host: about 12 ring voxels of travel; 0 where this LOD cannot stage bricks)
-                // (doubled while the host's hint holds: rays nearly parallel to x make flat boxes, and the
-                // staged bytes per sample fall with the slab length; first misfit: back to the plain length)
-                while (brick_mode && L.slab > 0 && run >= (L.slab << (brick_mode >> 1)) / U) {
-                    const int slab = L.slab << (brick_mode >> 1);
+                // (a wave starts with slabs of twice that length: the staged bytes per sample fall with the slab
+                // length; at its first box that does not fit the LDS region it drops to the plain length)
+                while (brick_mode && L.slab > 0 && run >= (L.slab << (brick_mode - 1)) / U) {
+                    const int slab = L.slab << (brick_mode - 1);
                     const bool live = alive && !finished && n < nsteps;
                     // first and last existing sample of the slab, both at once with the packed chain
                     const float2_t it = { (float)n, (float)min(n + slab - 1, nsteps - 1) };
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const int ny = hy - ly + 1, nz = hz - lz + 1;
                     const int groups = (ny * nz) << lgx;
                     if (ny >= 512 || groups * 16 > kBrickBytes) {            // does not fit
-                        if (brick_mode == 2) { brick_mode = 1; continue; }    // retry at the plain slab length
+                        if (brick_mode > 1) { --brick_mode; continue; }       // retry with half the slab
                         brick_mode = 0; break;                                // march direct from here on
                     }
                     // One load instruction per (z plane, chunk of 64 >> lgx rows): a lane's source offset is

@@ -490,18 +490,9 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     const int brick_mask = P.brick_lod_mask;
-    {   // Central view direction in data space: the image of the NDC segment (0,0,-1)..(0,0,1).  Rays
-        // nearly parallel to x (the rings' contiguous axis) make flat slab boxes: start with long slabs.
-        const float n0[4] = { 0.f, 0.f, -1.f, 1.f }, f0[4] = { 0.f, 0.f, 1.f, 1.f };
-        float a[4], b[4];
-        mat_vec4(P.ndc_to_data, n0, a);
-        mat_vec4(P.ndc_to_data, f0, b);
-        float d[3], len = 0.f;
-        for (int k = 0; k < 3; ++k) { d[k] = b[k] / b[3] - a[k] / a[3]; len += d[k] * d[k]; }
-        len = sqrtf(len);
-        const bool along_x = len > 0.f && fabsf(d[0]) >= 0.94f * len;              // within ~20 degrees of x
-        P.slab_long = (along_x && !(c->variant & 4)) ? 1 : 0;                       // variant bit 2: never
-    }
+    // Every wave starts with brick slabs of twice the plain length (the staged bytes per sample fall with the
+    // slab length) and drops to the plain length at its first box that does not fit; variant bit 2: never long.
+    P.slab_long = (c->variant & 4) ? 0 : ((c->variant & 8) ? 2 : 1);              // bit 3: start at four times (experiment)
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
         float wx[4];

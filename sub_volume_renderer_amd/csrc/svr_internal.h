@@ -68,7 +68,7 @@ struct MarchParams {
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
-    int32_t slab_long;             // 1: brick slabs start at twice their plain length (view nearly along x)
+    int32_t slab_long;             // 1: brick slabs start at twice their plain length
     int32_t block_waves_log2;      // span kernel: block = (1 << this)^2 wave tiles (0: one wave per block)
     const uint32_t* tile_order;    // blockIdx -> tile index (null: contiguous run of tiles per XCD)
     int32_t dbg_nowait;            // experiments only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
