@@ -314,6 +314,20 @@ def main():
                               offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
                               shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
                               scale=tuple(float(v) for v in u["scale_factor"])))
+        # threads = the CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the
+        # GPU box shows 256 hardware threads but grants 16 CPUs' worth of time to a one-GPU job)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota_note = ""
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q, per = f.read().split()[:2]
+            if q != "max":
+                allowed = max(1, int(-(-int(q) // int(per))))
+                if allowed < cores:
+                    quota_note = f" (cgroup CPU quota: {allowed} of {cores} hardware threads)"
+                    cores = allowed
+        except (OSError, ValueError):
+            pass
         mats = spec.matrices()
         vdim = tuple(float(v) for v in vol._volume_dimensions)
         m_full = dict(spec.material)
@@ -321,7 +335,7 @@ def main():
         # calibrate on every 32nd row, then size the sample to ~cpu_seconds of oracle time
         cal = FrameRegion(0, 0, W, -(-H // 32), 1, 32)
         t = time.perf_counter()
-        ref = oracle_lmip.render(rings, mats, vdim, m_full, W, H, region=cal, nthreads=0)
+        ref = oracle_lmip.render(rings, mats, vdim, m_full, W, H, region=cal, nthreads=cores)
         t_cal = time.perf_counter() - t
         rate = max(1.0, ref.steps.astype(np.int64).sum() / t_cal)
         frac = min(1.0, args.cpu_seconds * rate / max(1, counts["full"]["steps"]))
@@ -336,16 +350,15 @@ def main():
             m["lmip_threshold"] = float("inf") if mode == "full" else 0.5 * 255.0
             t = time.perf_counter()
             for _ in range(reps if mode == "full" else 1):
-                ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=0)
+                ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=cores)
             dtc = time.perf_counter() - t
             k = reps if mode == "full" else 1
             base[mode] = (k * int(ref.steps.astype(np.int64).sum()), dtc, ref)
-        cores = oracle_lmip.lib().svr_oracle_max_threads()
         st, dtc, ref = base["full"]
         result["cpu_baseline"] = {
             "value": st / dtc / 1e6, "unit": "Mray-steps/s", "cores": cores, "kind": "port",
             "sample": f"{reps} pass(es) over every {stride}th row of the same frame ({nrows} rows; {st} ray-steps, {dtc:.1f} s of oracle time), "
-                      "full mode, all host cores (OpenMP); CPU restatement of the reference shader "
+                      f"full mode, {cores} OpenMP threads{quota_note}; CPU restatement of the reference shader "
                       "(the reference itself cannot run offline: pygfx/wgpu absent)",
         }
         if "lmip" in base:
