@@ -358,11 +358,6 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t shl_add(uint32_t a, uint32_t sh, uint32_t c) {   // (a << sh) + c
-    uint32_t r;
-    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(sh), "v"(c));
-    return r;
-}
 template <int SH>
 __device__ __forceinline__ uint32_t shl_add_c(uint32_t a, uint32_t c) {                // (a << SH) + c
     if (SH == 0) return a + c;
@@ -508,7 +503,6 @@ struct LodEvents {
 };
 
 // LDS brick geometry (u8 storage): one private region per wave
-constexpr int kSlab = 16;              // iterations per brick
 constexpr int kBrickBytes = 8192;      // per wave; 4 waves per block -> 32 KiB per block
 
 template <int NL, int U, bool COUNT, int ESH>

@@ -92,3 +92,45 @@ def test_max_byte_value_reaches_threshold_255():
     spec.material.update(lmip_threshold=255.0)
     _, ref, rep = check(testing.build(spec))
     assert rep["n_hit"] > 50
+
+
+def test_c_abi_rejects_bad_arguments_with_messages():
+    """Every entry point validates on the host and returns an error code + message; nothing reaches a kernel."""
+    import ctypes as C
+
+    lib = N.lib()
+    descs = (N.LodDesc * 1)()
+    descs[0].ring_dims[:] = (32, 16, 16)
+    descs[0].density_storage = 0                                   # SVR_U8
+    ctx = C.c_void_p()
+    assert lib.svr_create(0, 1, descs, C.byref(ctx)) == 0
+
+    def fails(rc, needle):
+        assert rc != 0
+        msg = lib.svr_last_error().decode()
+        assert needle in msg, msg
+
+    I3, L3 = C.c_int32 * 3, C.c_int64 * 3
+    st = N.LodState()
+    st.offset[:] = (0, 0, 0); st.shape[:] = (64, 16, 16); st.scale[:] = (1.0, 1.0, 1.0)
+    fails(lib.svr_set_lod_state(ctx, 0, C.byref(st)), "larger than the ring")
+    st.shape[:] = (16, 16, 16)
+    fails(lib.svr_set_lod_state(ctx, 3, C.byref(st)), "out of range")
+    assert lib.svr_set_lod_state(ctx, 0, C.byref(st)) == 0
+    data = np.zeros((16, 16, 64), np.uint8)
+    fails(lib.svr_upload_region(ctx, 0, I3(0, 0, 0), I3(64, 16, 16), C.c_void_p(data.ctypes.data), 0,
+                                L3(1, 64, 1024), None, 0, L3(0, 0, 0)), "svr_upload_region")
+    f32 = np.zeros((16, 16, 32), np.float32)
+    fails(lib.svr_upload_region(ctx, 0, I3(0, 0, 0), I3(32, 16, 16), C.c_void_p(f32.ctypes.data), 8,
+                                L3(4, 128, 2048), None, 0, L3(0, 0, 0)), "uint8")
+    cam, fr, ob = N.Camera(), N.Frame(), N.Outputs()
+    fr.frame_w, fr.frame_h, fr.out_w, fr.out_h, fr.band_h, fr.band_pitch = 8, 8, 8, 8, 8, 8
+    fails(lib.svr_render(ctx, C.byref(cam), C.byref(fr), C.byref(ob), None), "null argument")
+    import torch
+
+    out = torch.zeros((8, 8, 4), dtype=torch.float32, device="cuda")
+    ob.rgba = out.data_ptr()
+    fails(lib.svr_render(ctx, C.byref(cam), C.byref(fr), C.byref(ob), None), "svr_set_material")
+    m = N.Material()
+    fails(lib.svr_set_material(ctx, C.byref(m)), "at least one colour")
+    assert lib.svr_destroy(ctx) == 0
