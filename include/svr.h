@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 #define SVR_MAX_LODS 8
-#define SVR_ABI_VERSION 3
+#define SVR_MAX_CLIP_PLANES 8
+#define SVR_ABI_VERSION 4
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -79,6 +80,14 @@ typedef struct svr_material {
     uint32_t color_count;
     const float* colors;           /* host pointer, color_count * 4 floats */
     int32_t  colorspace_srgb;      /* 1: apply srgb2physical (raycast.wgsl:71-72; texture default) */
+    /* Material.clipping_planes / clipping_mode of pygfx (the `pygfx.clipping_planes.wgsl` include at
+     * fs_main.wgsl:8): world-space planes (a, b, c, d); the fragment — here: the whole ray, because the
+     * tested position is the interpolated world position of the proxy box's BACK face (vs_main.wgsl:27) —
+     * is discarded when dot(world_pos, abc) < d holds for ANY plane (clipping_mode_all = 0) or for ALL of
+     * them (1).  No planes (the default): nothing is clipped.  pygfx text restated: assumption A6. */
+    uint32_t clipping_plane_count; /* 0 .. SVR_MAX_CLIP_PLANES */
+    int32_t  clipping_mode_all;
+    const float* clipping_planes;  /* host pointer, clipping_plane_count * 4 floats (may be NULL when the count is 0) */
 } svr_material;
 
 /* == the six mat4 of u_stdinfo / u_wobject that the shaders read
@@ -184,6 +193,13 @@ int  svr_publish_uploads(svr_ctx* ctx);
  * svr_render never waits for marked-but-unpublished uploads. */
 int  svr_mark_uploads(svr_ctx* ctx);
 int  svr_uploads_pending(svr_ctx* ctx, int* pending);
+/* The same, for several loads in flight at once (one per LOD: the coarse levels are uploaded first and
+ * published as soon as THEY have landed, FUTURE.md:86-95): svr_upload_ticket records an event behind
+ * everything enqueued on the upload stream so far and returns its ticket (> 0); svr_ticket_pending
+ * reports 1 while that event has not been reached.  Tickets older than the 64 most recent ones are
+ * reported as done only after the oldest live one is (their event has been reused). */
+int  svr_upload_ticket(svr_ctx* ctx, uint64_t* ticket);
+int  svr_ticket_pending(svr_ctx* ctx, uint64_t ticket, int* pending);
 
 /* ---- readback of a ring region into packed host arrays (shader-order
  * shape, x fastest): the texture.data numpy mirror the reference's tests read

@@ -39,6 +39,7 @@ class _Material(C.Structure):
         ("lmip_threshold", C.c_float), ("lmip_fall_off", C.c_float), ("lmip_max_samples", C.c_int32),
         ("fog_density", C.c_float), ("fog_color", C.c_float * 3), ("color_count", C.c_uint32),
         ("colors", C.POINTER(C.c_float)), ("colorspace_srgb", C.c_int32),
+        ("clipping_plane_count", C.c_uint32), ("clipping_mode_all", C.c_int32), ("clipping_planes", C.POINTER(C.c_float)),
     ]
 
 
@@ -93,7 +94,9 @@ def _mat(m):
 
 
 DEFAULT_MATERIAL = dict(lmip_fall_off=0.5, lmip_max_samples=10, fog_density=0.5, fog_color=(0.5, 0.5, 0.5),
-                        colors=None, clim=(0, 1), gamma=1.0, opacity=1.0)       # _material.py:26-37
+                        colors=None, clim=(0, 1), gamma=1.0, opacity=1.0,       # _material.py:26-37
+                        clipping_planes=(), clipping_mode="ANY",                # pygfx Material defaults
+                        render_mode="lmip")
 DEFAULT_COLORS = [(0.0, 1.0, 1.0), (0.25, 1.0, 1.0), (0.5, 1.0, 1.0), (0.75, 1.0, 1.0)]  # _material.py:51-57
 
 
@@ -109,10 +112,19 @@ def render(rings, matrices, volume_dimensions_shader, material, width, height, r
     cm.gamma = float(m["gamma"]); cm.opacity = float(m["opacity"])
     cm.lmip_threshold = float(m["lmip_threshold"]); cm.lmip_fall_off = float(m["lmip_fall_off"])
     cm.lmip_max_samples = int(m["lmip_max_samples"]); cm.fog_density = float(m["fog_density"])
+    if m["render_mode"] == "mip":
+        # MIP (FUTURE.md:97-120; pygfx's own volume raycast without its refinement) through raycast.wgsl:35-61:
+        # the first sample is significant (|s| >= -inf), every larger one replaces it (strict >, :50), and the
+        # loop never breaks (:58: since < 2^31 - 1, |s| < max * 0 is false).  lmip_numpy.py states MIP directly.
+        cm.lmip_threshold, cm.lmip_fall_off, cm.lmip_max_samples = float("-inf"), 0.0, 2**31 - 1
     cm.fog_color[:] = [float(v) for v in m["fog_color"]]
     cm.color_count = len(col)
     cm.colors = col.ctypes.data_as(C.POINTER(C.c_float))
     cm.colorspace_srgb = 1 if colorspace_srgb else 0
+    planes = np.ascontiguousarray(np.array(m["clipping_planes"], np.float32).reshape(-1, 4))
+    cm.clipping_plane_count = len(planes)
+    cm.clipping_mode_all = 1 if str(m["clipping_mode"]).upper() == "ALL" else 0
+    cm.clipping_planes = planes.ctypes.data_as(C.POINTER(C.c_float))
 
     cam = _Camera()
     for k in ("world", "world_inv", "cam", "cam_inv", "proj", "proj_inv"):

@@ -69,6 +69,15 @@ def _render(rings, M, vdim, mat, W, H, srgb, pick_id=None):
     bw = _mv(world, back[0], back[1], back[2], one)
     bc = _mv(pc, bw[0], bw[1], bw[2], bw[3])
     frag &= (bc[3] > 0) & (bc[2] >= 0) & (bc[2] <= bc[3])
+    # fs_main.wgsl:8, pygfx.clipping_planes.wgsl (restated, assumption A6): discard where the back-face world
+    # position lies behind ANY / ALL planes: dot(world_pos, abc) < d
+    planes = np.array(mat.get("clipping_planes", ()), f32).reshape(-1, 4)
+    if len(planes):
+        behind = [((bw[0] * p[0] + bw[1] * p[1]) + bw[2] * p[2]) < p[3] for p in planes]
+        if str(mat.get("clipping_mode", "ANY")).upper() == "ALL":
+            frag &= ~np.logical_and.reduce(behind)
+        else:
+            frag &= ~np.logical_or.reduce(behind)
     nb = [near[k] - back[k] for k in range(3)]
     dist = (nb[0] * ray[0] + nb[1] * ray[1]) + nb[2] * ray[2]
     for k in range(3):
@@ -111,8 +120,29 @@ def _render(rings, M, vdim, mat, W, H, srgb, pick_id=None):
             done |= inb
         return val
 
+    mip = str(mat.get("render_mode", "lmip")) == "mip"
     it = 0
-    while True:
+    while mip:
+        # MIP stated directly (not through the LMIP state machine): the largest |sample| of the whole ray,
+        # first occurrence; every fragment "finds" one (its first sample starts the running maximum)
+        act = frag & (it < nsteps)
+        if not act.any():
+            break
+        idx = np.nonzero(act)
+        off = [f32(it) * step[k][idx] for k in range(3)]
+        coord = [start[k][idx] + off[k] for k in range(3)]
+        s = texel_index(coord, labels=False)
+        inten = np.abs(s)
+        steps[idx] += 1
+        better = ~found[idx] | (inten > lmax[idx])
+        lmax[idx] = np.where(better, inten, lmax[idx])
+        samp[idx] = np.where(better, s, samp[idx])
+        for k in range(3):
+            hit_off[k][idx] = np.where(better, off[k], hit_off[k][idx])
+            hit_coord[k][idx] = np.where(better, coord[k], hit_coord[k][idx])
+        found[idx] = True
+        it += 1
+    while not mip:
         act = ~finished & (it < nsteps)
         if not act.any():
             break

@@ -190,6 +190,25 @@ static int shade_pixel(const frame_ctx* F, int W, int H, int i, int j,
     v4 bc = mat_vec(F->pc, bw);
     if (!(bc.w > 0.0f) || !(bc.z >= 0.0f) || !(bc.z <= bc.w)) return SVR_PIX_DISCARD;
 
+    /* fs_main.wgsl:8  {$ include 'pygfx.clipping_planes.wgsl' $}  (pygfx 0.12, third party, restated from its
+     * published text — assumption A6): with n_clipping_planes > 0
+     *     var clipped = (clipping_mode == 'ANY') ? false : true;
+     *     for each plane: plane_clipped = dot(varyings.world_pos, plane.xyz) < plane.w;
+     *                     clipped = clipped || plane_clipped   (ANY)   /   clipped && plane_clipped   (ALL)
+     *     if (clipped) { discard; }
+     * varyings.world_pos is the world position of the BACK-face fragment (vs_main.wgsl:27), so a clipped
+     * fragment removes the whole ray.  No planes (the default): the include expands to nothing. */
+    if (M->clipping_plane_count > 0) {
+        int clipped = M->clipping_mode_all ? 1 : 0;
+        for (uint32_t k = 0; k < M->clipping_plane_count; ++k) {
+            const float* pl = M->clipping_planes + 4u * k;
+            v3 wpos = { bw.x, bw.y, bw.z }, abc = { pl[0], pl[1], pl[2] };
+            int plane_clipped = dot3(wpos, abc) < pl[3];
+            clipped = M->clipping_mode_all ? (clipped && plane_clipped) : (clipped || plane_clipped);
+        }
+        if (clipped) return SVR_PIX_DISCARD;
+    }
+
     /* fs_main.wgsl:32-35 */
     v3 nb = { near_pos.x - back.x, near_pos.y - back.y, near_pos.z - back.z };
     float dist = dot3(nb, ray);

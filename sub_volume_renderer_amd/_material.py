@@ -70,6 +70,10 @@ class SubVolumeMaterial:
         self._u = {}
         self._version = 0
         self.depth_test = True          # the reference insists on depth testing (_material.py:39-45)
+        # inherited from pygfx's Material: no clipping planes unless the caller sets some
+        self.clipping_planes = ()
+        self.clipping_mode = "ANY"
+        self.render_mode = "lmip"
         arguments = dict(clim=clim, gamma=gamma, opacity=opacity, lmip_threshold=lmip_threshold,
                          lmip_fall_off=lmip_fall_off, lmip_max_samples=lmip_max_samples, fog_density=fog_density,
                          fog_color=fog_color,
@@ -112,6 +116,63 @@ class SubVolumeMaterial:
         if packed.min() < 0.0 or packed.max() > 1.0:
             raise ValueError("fog_color components must lie in [0, 1]")
         self._store("fog_color", packed)
+
+    # -- clipping planes (pygfx Material; the shader includes pygfx.clipping_planes.wgsl, fs_main.wgsl:8) ----
+    MAX_CLIPPING_PLANES = 8
+
+    @property
+    def clipping_planes(self) -> list[tuple[float, float, float, float]]:
+        """World-space planes (a, b, c, d).  The draw skips a pixel whose ray leaves the volume's box at a
+        point p with ``dot(p, abc) < d`` for ANY plane (``clipping_mode == "ANY"``) or for ALL of them."""
+        return [tuple(map(float, row)) for row in self._u["clipping_planes"]]
+
+    @clipping_planes.setter
+    def clipping_planes(self, planes) -> None:
+        rows = []
+        for plane in planes:
+            if isinstance(plane, (str, bytes)) or len(plane) != 4:
+                raise TypeError(f"Each clipping plane must be an abcd tuple, not {plane}")
+            rows.append([float(v) for v in plane])
+        if len(rows) > self.MAX_CLIPPING_PLANES:
+            raise ValueError(f"at most {self.MAX_CLIPPING_PLANES} clipping planes are supported")
+        self._store("clipping_planes", np.asarray(rows, np.float32).reshape(-1, 4))
+
+    @property
+    def clipping_mode(self) -> str:
+        """"ANY": a point is clipped if it is behind any plane; "ALL": only if it is behind all of them."""
+        return self._u["clipping_mode"]
+
+    @clipping_mode.setter
+    def clipping_mode(self, mode) -> None:
+        mode = str(mode).upper()
+        if mode not in ("ANY", "ALL"):
+            raise ValueError(f"Unexpected clipping_mode: {mode}")
+        self._store("clipping_mode", mode)
+
+    # -- render mode: the swappable raycast the reference wishes for (FUTURE.md:97-120) -------------------------
+    RENDER_MODES = ("lmip", "mip")
+
+    @property
+    def render_mode(self) -> str:
+        """"lmip" (the reference's raycast.wgsl) or "mip": the maximum over the WHOLE ray, first occurrence —
+        what pygfx's own ``VolumeMipMaterial`` raycast selects (without its sub-step refinement).  MIP is the
+        LMIP state machine with every sample significant, no fall-off and no sample limit, so it runs on the
+        same kernel: the draw sends threshold = -inf, fall_off = 0, max_samples = 2**31 - 1 and leaves the
+        ``lmip_*`` properties untouched."""
+        return self._u["render_mode"]
+
+    @render_mode.setter
+    def render_mode(self, mode) -> None:
+        mode = str(mode).lower()
+        if mode not in self.RENDER_MODES:
+            raise ValueError(f"render_mode must be one of {self.RENDER_MODES}, not {mode!r}")
+        self._store("render_mode", mode)
+
+    def lmip_uniforms(self) -> tuple[float, float, int]:
+        """(threshold, fall_off, max_samples) as the draw sends them for the current render mode."""
+        if self._u["render_mode"] == "mip":
+            return float("-inf"), 0.0, 2**31 - 1
+        return float(self._u["lmip_threshold"]), float(self._u["lmip_fall_off"]), int(self._u["lmip_max_samples"])
 
     # -- label hues: list of (h, s, v); stored vec4-padded like the reference's n*4xf4 array (:119-159) ---
     @property

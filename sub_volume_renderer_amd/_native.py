@@ -39,7 +39,7 @@ class LodDesc(C.Structure):
     _fields_ = [("ring_dims", C.c_int32 * 3), ("density_storage", C.c_int32)]
 
 
-SVR_U8, SVR_F32 = 0, 8
+SVR_U8, SVR_U16, SVR_F32 = 0, 1, 8
 
 
 class LodState(C.Structure):
@@ -59,6 +59,9 @@ class Material(C.Structure):
         ("color_count", C.c_uint32),
         ("colors", C.POINTER(C.c_float)),
         ("colorspace_srgb", C.c_int32),
+        ("clipping_plane_count", C.c_uint32),
+        ("clipping_mode_all", C.c_int32),
+        ("clipping_planes", C.POINTER(C.c_float)),
     ]
 
 
@@ -118,6 +121,8 @@ SIGNATURES = {
     "svr_publish_uploads": (C.c_int, [C.c_void_p]),
     "svr_mark_uploads": (C.c_int, [C.c_void_p]),
     "svr_uploads_pending": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "svr_upload_ticket": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "svr_ticket_pending": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]),
     "svr_read_region": (C.c_int, [C.c_void_p, C.c_int, _I3, _I3, C.c_void_p, C.c_void_p]),
     "svr_clear_lod": (C.c_int, [C.c_void_p, C.c_int]),
     "svr_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),

@@ -79,36 +79,31 @@ class SubVolume(_HasWorld):
         ring_storage: str = "native",
     ):
         super().__init__()
-        base_data = data_segmentation_pairs[0][0]
-        num_scales = len(data_segmentation_pairs)
+        pairs = list(data_segmentation_pairs)
+        levels = len(pairs)
+        finest = pairs[0][0]
 
-        # one shape for all scales (tuple) or one per scale (list) — _wobject.py:34-63
-        if isinstance(buffer_shape_in_chunks, tuple):
-            buffer_shapes = [buffer_shape_in_chunks] * num_scales
-        else:
-            buffer_shapes = buffer_shape_in_chunks
-            if len(buffer_shapes) != num_scales:
-                raise ValueError(
-                    f"buffer_shape_in_chunks list length ({len(buffer_shapes)}) must match number of scales ({num_scales})"
-                )
+        # One value for every scale (a tuple) or one value per scale (any other sequence, whose length
+        # must then equal the number of scales) — the two spellings the reference accepts (_wobject.py:34-63).
+        def per_scale(value, name):
+            if isinstance(value, tuple):
+                return [value] * levels
+            if len(value) != levels:
+                raise ValueError(f"{name} list length ({len(value)}) must match number of scales ({levels})")
+            return value
+
+        buffer_shapes = per_scale(buffer_shape_in_chunks, "buffer_shape_in_chunks")
         if chunk_shape_in_pixels is None:
-            if hasattr(base_data, "chunks"):
-                chunk_shapes = [base_data.chunks] * num_scales
-            else:
-                raise ValueError(
-                    "if chunk_shape_in_pixels is not provided, base data must have a 'chunks' attribute"
-                )
-        elif isinstance(chunk_shape_in_pixels, tuple):
-            chunk_shapes = [chunk_shape_in_pixels] * num_scales
-        else:
-            chunk_shapes = chunk_shape_in_pixels
-            if len(chunk_shapes) != num_scales:
-                raise ValueError(
-                    f"chunk_shape_in_pixels list length ({len(chunk_shapes)}) must match number of scales ({num_scales})"
-                )
-        for i, (scale_data, _) in enumerate(data_segmentation_pairs):
-            if len(chunk_shapes[i]) != scale_data.ndim:
-                raise ValueError(f"chunk_shape_in_pixels[{i}] length must match data dimensions")
+            # chunked array types (zarr, tensorstore) know their own chunking (_wobject.py:46-53)
+            native = getattr(finest, "chunks", None)
+            if native is None:
+                raise ValueError("if chunk_shape_in_pixels is not provided, base data must have a 'chunks' attribute")
+            chunk_shape_in_pixels = tuple(native)
+        chunk_shapes = per_scale(chunk_shape_in_pixels, "chunk_shape_in_pixels")
+        for level, ((density, _), chunk) in enumerate(zip(pairs, chunk_shapes)):
+            if len(chunk) != density.ndim:
+                raise ValueError(f"chunk_shape_in_pixels[{level}] length must match data dimensions")
+        data_segmentation_pairs, num_scales, base_data = pairs, levels, finest
         if num_scales > N.SVR_MAX_LODS:
             raise ValueError(f"at most {N.SVR_MAX_LODS} scales are supported")
 
@@ -197,12 +192,15 @@ class SubVolume(_HasWorld):
             )
         # world -> data space; the matrix works in shader order, so reverse to numpy order
         p = (self.world.inverse_matrix @ np.array([*position, 1.0]))[:3][::-1]
+        if not asynchronous and self._submitted != self._completed:
+            self.poll_uploads(wait=True)                  # never interleave a blocking load with the worker's
         jobs = []
         for size, buffer in zip(sizes, self.wrapping_buffers):
             offset = tuple(int(c * f - s // 2) for c, s, f in zip(p, size, buffer.scale_factor))
             roi = Roi(offset, size)
             if buffer.can_load_logical_roi(roi):
                 if asynchronous:
+                    buffer._async_focus = tuple(c * f for c, f in zip(p, buffer.scale_factor))
                     pieces = buffer.begin_async_load(roi)
                     if pieces:
                         jobs.append((buffer, pieces))
@@ -212,51 +210,94 @@ class SubVolume(_HasWorld):
             self._submit_uploads(jobs)
 
     # -- asynchronous streaming ------------------------------------------------------
+    @staticmethod
+    def _prioritise(jobs):
+        """Upload order "low res near > low res far > high res near > high res far" (FUTURE.md:86-95): the
+        coarsest level first — it covers the most space, and it is what the sampler falls back to while a
+        finer level's window is shrunk — and inside a level the pieces nearest to the camera first."""
+        ordered = []
+        for buffer, pieces in sorted(jobs, key=lambda job: -job[0]._lod):
+            focus = getattr(buffer, "_async_focus", None)
+            if focus is not None:
+                chunk = buffer.chunk_shape_in_pixels
+
+                def distance2(piece, focus=focus, chunk=chunk):
+                    roi = piece[1]                                           # logical ROI in chunks
+                    return sum(((b + 0.5 * n) * c - f) ** 2 for b, n, c, f in zip(roi.begin, roi.shape, chunk, focus))
+
+                pieces = sorted(pieces, key=distance2)
+            ordered.append((buffer, pieces))
+        return ordered
+
     def _submit_uploads(self, jobs):
         import queue
         import threading
 
-        self._rings.handle                                # create the context on this thread
+        handle = self._rings.handle                       # create the context on this thread
+        for b in self.wrapping_buffers:
+            b._async_owner = self
         if self._worker is None:
             self._jobs = queue.Queue()
 
             def run():
+                lib = N.lib()
                 while True:
                     item = self._jobs.get()
                     if item is None:
                         return
+                    buffer, pieces = item
+                    ticket, error = C.c_uint64(0), None
                     try:
-                        for buffer, pieces in item:
-                            for buffer_roi, logical_roi in pieces:
-                                buffer.load_into_buffer(buffer_roi, logical_roi)
-                        N.check(N.lib().svr_mark_uploads(self._rings.handle), "svr_mark_uploads")
-                    except BaseException as exc:  # surfaced by poll_uploads on the render thread
-                        self._worker_error = exc
-                    finally:
-                        self._inflight.append(item)
+                        for buffer_roi, logical_roi in pieces:
+                            buffer.load_into_buffer(buffer_roi, logical_roi)
+                        N.check(lib.svr_upload_ticket(handle, C.byref(ticket)), "svr_upload_ticket")
+                    except BaseException as exc:          # surfaced by poll_uploads on the render thread
+                        error = exc
+                    self._inflight.append((buffer, ticket.value, error))
 
             self._worker = threading.Thread(target=run, name="svr-upload", daemon=True)
             self._worker.start()
-        self._submitted += 1
-        self._jobs.put(jobs)
+        # one job per level, coarse levels first: each gets its own ticket and is published as soon as
+        # ITS chunks have landed
+        for job in self._prioritise(jobs):
+            self._submitted += 1
+            self._jobs.put(job)
 
     def poll_uploads(self, wait: bool = False) -> bool:
         """Publish the full ROI of every asynchronous load whose chunks have landed in HBM.
-        Returns True when nothing is in flight any more."""
+        Returns True when nothing is in flight any more.  An exception raised by a backing array on the
+        worker thread is re-raised here, once; that level keeps its shrunk window and re-plans next time."""
         import time
 
+        lib = N.lib()
         while True:
-            if self._worker_error is not None:
-                err, self._worker_error = self._worker_error, None
-                raise err
-            while self._inflight and self._submitted > self._completed:
-                pending = C.c_int(0)
-                N.check(N.lib().svr_uploads_pending(self._rings.handle, C.byref(pending)), "svr_uploads_pending")
-                if pending.value:
-                    break
-                for buffer, _ in self._inflight.pop(0):
-                    buffer.finish_async_load()
+            errors, replay = [], []
+            while self._inflight:
+                buffer, ticket, error = self._inflight[0]
+                if error is None:
+                    pending = C.c_int(0)
+                    N.check(lib.svr_ticket_pending(self._rings.handle, ticket, C.byref(pending)), "svr_ticket_pending")
+                    if pending.value:
+                        break
+                self._inflight.pop(0)
                 self._completed += 1
+                if error is None:
+                    wanted = buffer.finish_async_load()
+                else:
+                    errors.append(error)
+                    wanted = buffer.abort_async_load()
+                if wanted is not None:
+                    replay.append((buffer, wanted))
+            jobs = []
+            for buffer, roi in replay:                     # requests that arrived meanwhile: the latest one wins
+                if buffer.can_load_logical_roi(roi):
+                    pieces = buffer.begin_async_load(roi)
+                    if pieces:
+                        jobs.append((buffer, pieces))
+            if jobs:
+                self._submit_uploads(jobs)
+            if errors:
+                raise errors[0]
             if self._submitted == self._completed or not wait:
                 return self._submitted == self._completed
             time.sleep(0.0002)
@@ -271,9 +312,7 @@ class SubVolume(_HasWorld):
         cm.clim[:] = [float(u["clim"][0]), float(u["clim"][1])]
         cm.gamma = float(u["gamma"])
         cm.opacity = float(u["opacity"])
-        cm.lmip_threshold = float(u["lmip_threshold"])
-        cm.lmip_fall_off = float(u["lmip_fall_off"])
-        cm.lmip_max_samples = int(u["lmip_max_samples"])
+        cm.lmip_threshold, cm.lmip_fall_off, cm.lmip_max_samples = m.lmip_uniforms()
         cm.fog_density = float(u["fog_density"])
         cm.fog_color[:] = [float(v) for v in u["fog_color"]]
         colors = np.ascontiguousarray(u["colors"], np.float32)
@@ -281,6 +320,10 @@ class SubVolume(_HasWorld):
         cm.colors = colors.ctypes.data_as(C.POINTER(C.c_float))
         # _shader.py:68: colorspace of the first texture; 'srgb' selects srgb2physical
         cm.colorspace_srgb = 1 if self.textures[0].colorspace == "srgb" else 0
+        planes = np.ascontiguousarray(u["clipping_planes"], np.float32)
+        cm.clipping_plane_count = int(planes.shape[0])
+        cm.clipping_mode_all = 1 if u["clipping_mode"] == "ALL" else 0
+        cm.clipping_planes = planes.ctypes.data_as(C.POINTER(C.c_float))
         N.check(N.lib().svr_set_material(self._rings.handle, C.byref(cm)), "svr_set_material")
         self._material_version_pushed = m._version
 

@@ -39,8 +39,8 @@ class DeviceRings:
         self.device = device
         # "float32": the reference's r32float texture.  "uint8": byte rings for uint8 sources
         # (values 0..255 are exact in f32, so every sample and result is identical)
-        if density_storage not in ("float32", "uint8"):
-            raise ValueError("density_storage must be 'float32' or 'uint8'")
+        if density_storage not in ("float32", "uint8", "uint16"):
+            raise ValueError("density_storage must be 'float32', 'uint8' or 'uint16'")
         self.density_storage = density_storage
         self._handle = None
 
@@ -51,7 +51,7 @@ class DeviceRings:
             descs = (N.LodDesc * len(self.ring_shapes))()
             for d, s in zip(descs, self.ring_shapes):
                 d.ring_dims[:] = s[::-1]
-                d.density_storage = N.SVR_U8 if self.density_storage == "uint8" else N.SVR_F32
+                d.density_storage = {"uint8": N.SVR_U8, "uint16": N.SVR_U16}.get(self.density_storage, N.SVR_F32)
             device = self.device
             if device is None:
                 import torch
@@ -121,16 +121,19 @@ def _is_device_tensor(a) -> bool:
 
 
 def native_density_storage(arrays, ring_storage: str = "native") -> str:
-    """Ring element type for a set of backing density arrays: bytes when every source is uint8."""
+    """Ring element type for a set of backing density arrays: the sources' own type when every one of
+    them is uint8 (or every one uint16) — such values are exact in f32, so every result is identical to the
+    reference's r32float layout at a quarter (half) of the bytes — else float32."""
     if ring_storage not in ("native", "float32"):
         raise ValueError("ring_storage must be 'native' or 'float32'")
     if ring_storage == "float32":
         return "float32"
-    for a in arrays:
-        dt = str(getattr(a, "dtype", "")).replace("torch.", "")
-        if dt != "uint8":
-            return "float32"
-    return "uint8"
+    kinds = {str(getattr(a, "dtype", "")).replace("torch.", "") for a in arrays}
+    if kinds == {"uint8"}:
+        return "uint8"
+    if kinds == {"uint16"}:
+        return "uint16"
+    return "float32"
 
 
 # ---------------------------------------------------------------------------
@@ -176,6 +179,8 @@ class WrappingBuffer:
 
         self._roi_px: Roi | None = None
         self._pending_async = None
+        self._wanted_roi = None          # newest request that arrived while an asynchronous load was in flight
+        self._async_owner = None         # the SubVolume whose upload worker serves this buffer
         self._current_logical_roi_in_chunks: Roi | None = None
         self._scale_factor = (1.0, 1.0, 1.0)
         self._state_dirty = True
@@ -261,6 +266,10 @@ class WrappingBuffer:
         Only chunks not already resident are uploaded.  Too-large or empty
         requests are silently ignored and leave the state untouched (:171-172).
         """
+        if self._pending_async is not None:
+            # an asynchronous load of this ring is still streaming in: let it land (and be published) first,
+            # so that this load diffs against what is really resident and the two never interleave
+            self._drain_async()
         plan = self.plan_logical_roi(logical_roi_in_pixels)
         if plan is None:
             return
@@ -271,6 +280,12 @@ class WrappingBuffer:
             self.load_into_buffer(buffer_roi, logical_roi)
         self.publish()
 
+    def _drain_async(self):
+        owner = self._async_owner
+        if owner is None:
+            raise RuntimeError("an asynchronous load is pending on this buffer and nobody owns it")
+        owner.poll_uploads(wait=True)
+
     def begin_async_load(self, logical_roi_in_pixels: Roi):
         """First half of an asynchronous ``load_logical_roi``: plan the load, publish the SHRUNK ROI
         (old ROI intersected with the new one) and return the upload pieces for a worker thread.
@@ -278,10 +293,13 @@ class WrappingBuffer:
         The ring slots the new chunks will overwrite belong to chunks outside that intersection, so
         renders enqueued from now on never read a slot while it is being rewritten (the tearing the
         reference documents in FUTURE.md:60-67); coarser LODs cover the gap meanwhile.  Returns
-        ``None`` for the silent no-op cases and while a previous asynchronous load is still in flight.
+        ``None`` for the silent no-op cases.  While a previous asynchronous load is still in flight
+        the request is only remembered (the latest one wins) and replayed by :meth:`finish_async_load`.
         """
         if self._pending_async is not None:
+            self._wanted_roi = logical_roi_in_pixels
             return None
+        self._wanted_roi = None
         plan = self.plan_logical_roi(logical_roi_in_pixels)
         if plan is None:
             return None
@@ -297,16 +315,32 @@ class WrappingBuffer:
             shrunk = None if inter.empty else inter
         self._current_logical_roi_in_pixels = shrunk      # what the sampler may see while chunks stream in
         self._current_logical_roi_in_chunks = in_chunks   # what will be resident: later plans diff against it
-        self._pending_async = (snapped, pieces)
+        self._pending_async = (snapped, pieces, shrunk)
         return pieces
 
     def finish_async_load(self):
-        """Second half: all chunks are in HBM — publish the full new ROI."""
+        """Second half: all chunks are in HBM — publish the full new ROI.  Returns the ROI of a request
+        that arrived while this load was in flight (the caller starts it next), else ``None``."""
         if self._pending_async is None:
-            return
-        snapped, _ = self._pending_async
+            return None
+        snapped = self._pending_async[0]
         self._pending_async = None
         self._current_logical_roi_in_pixels = snapped
+        wanted, self._wanted_roi = self._wanted_roi, None
+        return wanted
+
+    def abort_async_load(self):
+        """The upload of an asynchronous load failed part-way: the new chunks are NOT all resident.  Keep the
+        shrunk ROI published (every slot it maps still holds its old chunk: the pieces only overwrite slots
+        outside it) and forget the rest, so that the next request re-plans and re-fetches what is missing."""
+        if self._pending_async is None:
+            return None
+        shrunk = self._pending_async[2]
+        self._pending_async = None
+        self._current_logical_roi_in_pixels = shrunk
+        self._current_logical_roi_in_chunks = None if shrunk is None else shrunk / self.chunk_shape_in_pixels
+        wanted, self._wanted_roi = self._wanted_roi, None
+        return wanted
 
     def publish(self):
         """Order the uploads before later renders and push the new ROI uniform."""

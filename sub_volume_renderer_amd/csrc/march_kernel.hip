@@ -57,8 +57,9 @@ __device__ __forceinline__ float sample_density(const MarchParams& P, float cx, 
     for (int l = 0; l < NL; ++l) {
         size_t idx;
         if (lod_texel(P.lod[l], dx, dy, dz, idx))
-            return P.density_u8 ? (float)static_cast<const uint8_t*>(P.lod[l].density)[idx]
-                                : static_cast<const float*>(P.lod[l].density)[idx];
+            return P.density_esh == 0 ? (float)static_cast<const uint8_t*>(P.lod[l].density)[idx]
+                 : P.density_esh == 1 ? (float)static_cast<const uint16_t*>(P.lod[l].density)[idx]
+                                      : static_cast<const float*>(P.lod[l].density)[idx];
     }
     return 0.0f;
 }
@@ -110,6 +111,22 @@ __device__ __forceinline__ float srgb2physical(float c) {
     return (c <= 0.04045f) ? t : f;
 }
 
+// The kernel's own argument block through a pointer the optimiser cannot see through: uniforms read this
+// way are loaded where they are used and die there, instead of occupying SGPRs for the whole march loop
+// (the SGPR file is what limits this kernel, not the VGPRs).  The pointer stays in the constant address
+// space, so a read at a wave-uniform index is one scalar load.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const MarchParams __attribute__((address_space(4)))* kparams_t;
+__device__ __forceinline__ kparams_t fresh_params(const MarchParams&) {
+    kparams_t p = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#else
+typedef const MarchParams* kparams_t;
+__device__ inline kparams_t fresh_params(const MarchParams& P) { return &P; }
+#endif
+
 struct Ray {
     f3 start, step;     // normalised coords (fs_main.wgsl:47-48)
     int nsteps;
@@ -142,6 +159,19 @@ __device__ __forceinline__ bool setup_ray(const MarchParams& P, int i, int j, Ra
     f4 bw = mat_vec(P.world, back.x, back.y, back.z, 1.0f);
     f4 bc = mat_vec(P.pc, bw.x, bw.y, bw.z, bw.w);
     if (!(bc.w > 0.0f) || !(bc.z >= 0.0f) || !(bc.z <= bc.w)) return false;   // outside clip volume
+    // pygfx.clipping_planes.wgsl (fs_main.wgsl:8): the fragment's varyings.world_pos is the world position
+    // of the back face (vs_main.wgsl:27); discard when it lies behind ANY / ALL of the material's planes
+    if (P.clip_count) {
+        const kparams_t Pc = fresh_params(P);
+        const uint32_t nplanes = Pc->clip_count;
+        const bool all = Pc->clip_all != 0;
+        bool clipped = all;
+        for (uint32_t k = 0; k < nplanes; ++k) {
+            const bool behind = ((bw.x * Pc->clip[k][0] + bw.y * Pc->clip[k][1]) + bw.z * Pc->clip[k][2]) < Pc->clip[k][3];
+            clipped = all ? (clipped && behind) : (clipped || behind);
+        }
+        if (clipped) return false;
+    }
 
     f3 nb = { near_pos.x - back.x, near_pos.y - back.y, near_pos.z - back.z };
     float dist = dot3(nb, ray);                                               // :32
@@ -338,6 +368,7 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, 
 // widened to f32 (exactly) only where the LMIP state machine needs the value.
 template <int ESH> struct Texel { typedef float type; };
 template <> struct Texel<0> { typedef uint32_t type; };
+template <> struct Texel<1> { typedef uint32_t type; };
 __device__ __forceinline__ float texel_value(float t) { return t; }
 __device__ __forceinline__ float texel_value(uint32_t t) { return (float)t; }
 __device__ __forceinline__ float texel_abs(float t) { return fabsf(t); }
@@ -349,6 +380,7 @@ __device__ __forceinline__ uint32_t texel_max(uint32_t a, uint32_t b) { return m
 template <int ESH>
 __device__ __forceinline__ typename Texel<ESH>::type fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
     if constexpr (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+    else if constexpr (ESH == 1) return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)off, 0, 0);
     else return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, 0, 0);
 }
 
@@ -461,22 +493,6 @@ __device__ __forceinline__ int wave_reduce(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// The kernel's own argument block through a pointer the optimiser cannot see through: uniforms read this
-// way are loaded where they are used and die there, instead of occupying SGPRs for the whole march loop
-// (the SGPR file is what limits this kernel, not the VGPRs).  The pointer stays in the constant address
-// space, so a read at a wave-uniform index is one scalar load.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const MarchParams __attribute__((address_space(4)))* kparams_t;
-__device__ __forceinline__ kparams_t fresh_params(const MarchParams&) {
-    kparams_t p = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-#else
-typedef const MarchParams* kparams_t;
-__device__ inline kparams_t fresh_params(const MarchParams& P) { return &P; }
-#endif
-
 // The uniforms of one LOD that the march loop needs (MarchParams::lod[l], read through fresh_params)
 struct LodK {
     uint32_t ring[3];
@@ -551,10 +567,13 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         }
     };
 
-    Ray R;
-    R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
-    const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
-    const int nsteps = frag ? R.nsteps : 0;
+    // (the ray lives in registers: it is assembled from selects, never written through a pointer under a branch)
+    Ray Rs;
+    Rs.nsteps = 0; Rs.start = { 0.f, 0.f, 0.f }; Rs.step = { 0.f, 0.f, 0.f };
+    const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, Rs);
+    const int nsteps = frag ? Rs.nsteps : 0;
+    const Ray R = { { frag ? Rs.start.x : 0.f, frag ? Rs.start.y : 0.f, frag ? Rs.start.z : 0.f },
+                    { frag ? Rs.step.x : 0.f, frag ? Rs.step.y : 0.f, frag ? Rs.step.z : 0.f }, nsteps };
 
     // ---- exact per-LOD event iterations
     // ic is monotone along the ray, so its values at the first and last sample bound every other
@@ -626,14 +645,14 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // `live`: this lane executes the batch; `tail`: some of its samples may lie beyond nsteps.
     // Skipped entirely while no lane can change state (nothing found yet, nothing >= threshold).
     typedef typename Texel<ESH>::type texel_t;
-    // "(f32)m >= threshold" on the raw texel: bytes compare as integers against ceil(threshold)
-    // (P.lmip_threshold_u8, 256 when no byte can reach it), f32 texels against the threshold itself
+    // "(f32)m >= threshold" on the raw texel: integer texels compare as integers against ceil(threshold)
+    // (P.lmip_threshold_raw, one past the largest value when none can reach it), f32 texels against the threshold itself
     texel_t thr_raw;
-    if constexpr (ESH == 0) thr_raw = P.lmip_threshold_u8; else thr_raw = P.lmip_threshold;
+    if constexpr (ESH != 2) thr_raw = P.lmip_threshold_raw; else thr_raw = P.lmip_threshold;
     auto lmip_batch = [&](const texel_t (&sv)[U], int nb, bool live, bool tail) {
         // u8: 0 is neutral (a live lane always has one real sample); f32: -1 < every |s|
         texel_t m;
-        if constexpr (ESH == 0) m = 0u; else m = -1.0f;
+        if constexpr (ESH != 2) m = 0u; else m = -1.0f;
         const texel_t neutral = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) m = texel_max(m, (tail && (nb + u) >= nsteps) ? neutral : texel_abs(sv[u]));
@@ -965,16 +984,19 @@ template <int NL>
 hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
-    const bool simple = kind == 1 || p.density_all_bytes == 0;   // >= 4 GiB of rings: 64-bit addressing
+    const bool simple = kind == 1 || p.density_all_bytes == 0;   // rings the 32-bit / 24-bit addressing of the span kernel cannot reach
     if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
         const int threads = 64 << (2 * p.block_waves_log2);
-        const size_t lds = p.density_u8 ? (size_t)kBrickBytes * (threads / 64) : 0;
-        if (p.density_u8) {
+        const size_t lds = p.density_esh == 0 ? (size_t)kBrickBytes * (threads / 64) : 0;
+        if (p.density_esh == 0) {
             if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
             else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
+        } else if (p.density_esh == 1) {
+            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 1>), dim3(nblocks), dim3(threads), lds, stream, p);
+            else         hipLaunchKernelGGL((march_span<NL, 8, false, 1>), dim3(nblocks), dim3(threads), lds, stream, p);
         } else {
             if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 2>), dim3(nblocks), dim3(threads), lds, stream, p);
             else         hipLaunchKernelGGL((march_span<NL, 8, false, 2>), dim3(nblocks), dim3(threads), lds, stream, p);

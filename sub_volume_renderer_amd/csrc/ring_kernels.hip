@@ -3,6 +3,8 @@
 // `texture.data[dst] = np.array(src, f32|u32)`, _wrapping_buffer.py:325-335),
 // the read-back gather, and the stripe un-tiler used after the RCCL gather.
 // All three are pure HBM streaming; rows (x) are the contiguous axis.
+#include <stdlib.h>
+
 #include "svr_internal.h"
 
 size_t svr_dtype_size(int dtype) {
@@ -50,8 +52,7 @@ __device__ __forceinline__ uint32_t load_as_u32(const char* p, int dtype) {
     }
 }
 
-// One thread per voxel, x fastest: loads and stores of a wave are contiguous
-// runs of the slab row / ring row.
+// General path: one thread per voxel, x fastest, any source dtype and strides (numpy cast semantics).
 __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
     const size_t n = (size_t)a.shape[0] * (size_t)a.shape[1] * (size_t)a.shape[2];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
         if (a.src_density) {
             const char* p = static_cast<const char*>(a.src_density) +
                             (int64_t)x * a.dstride[0] + (int64_t)y * a.dstride[1] + (int64_t)z * a.dstride[2];
-            if (a.ring_density_u8) static_cast<uint8_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint8_t*>(p);
+            if (a.ring_storage == SVR_U8) static_cast<uint8_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint8_t*>(p);
+            else if (a.ring_storage == SVR_U16) static_cast<uint16_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint16_t*>(p);
             else static_cast<float*>(a.ring_density)[dst] = load_as_f32(p, a.density_dtype);
         }
         if (a.src_labels) {
@@ -76,8 +78,45 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
     }
 }
 
+// Streaming path (the staged blocks of svr_upload_region and contiguous device sources): the source
+// rows are packed, already hold the ring's element types, and rows start and end on 16-voxel groups on
+// both sides.  One thread moves one group of 16 voxels with 16-byte loads and stores: DES bytes per
+// density element (1 / 2 / 4: 1 / 2 / 4 transfers) and 4 transfers for the u32 labels; no per-voxel
+// index arithmetic, no conversion.  Pure HBM streaming: 2 * 16 * (DES + 4) bytes per thread.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DES>
+__global__ __launch_bounds__(256) void scatter_rows16(const ScatterArgs a, uint32_t groups_per_row, uint32_t total) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t g = i % groups_per_row, row = i / groups_per_row;
+    const uint32_t y = row % (uint32_t)a.shape[1], z = row / (uint32_t)a.shape[1];
+    const size_t dst = ((size_t)(z + a.dst_off[2]) * (size_t)a.ring[1] + (size_t)(y + a.dst_off[1])) *
+                           (size_t)a.ring[0] + (size_t)(g * 16u + a.dst_off[0]);
+    if (a.src_density) {
+        const u32x4* s = reinterpret_cast<const u32x4*>(static_cast<const char*>(a.src_density) +
+                                                        (int64_t)y * a.dstride[1] + (int64_t)z * a.dstride[2]) + (size_t)g * DES;
+        u32x4* d = reinterpret_cast<u32x4*>(static_cast<char*>(a.ring_density) + dst * DES);
+        u32x4 v[DES];
+#pragma unroll
+        for (int k = 0; k < DES; ++k) v[k] = __builtin_nontemporal_load(s + k);      // staged bytes are read once
+#pragma unroll
+        for (int k = 0; k < DES; ++k) d[k] = v[k];
+    }
+    if (a.src_labels) {
+        const u32x4* s = reinterpret_cast<const u32x4*>(static_cast<const char*>(a.src_labels) +
+                                                        (int64_t)y * a.lstride[1] + (int64_t)z * a.lstride[2]) + (size_t)g * 4;
+        u32x4* d = reinterpret_cast<u32x4*>(a.ring_labels + dst);
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(s + k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = v[k];
+    }
+}
+
 struct GatherArgs {
-    const void* ring_density; int32_t ring_density_u8; const uint32_t* ring_labels;
+    const void* ring_density; int32_t ring_storage; const uint32_t* ring_labels;
     int32_t ring[3], off[3], shape[3];
     float* out_density; uint32_t* out_labels;
 };
@@ -93,8 +132,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const GatherArgs a) {
         const size_t src = ((size_t)(z + a.off[2]) * (size_t)a.ring[1] + (size_t)(y + a.off[1])) *
                                (size_t)a.ring[0] + (size_t)(x + a.off[0]);
         if (a.out_density)
-            a.out_density[i] = a.ring_density_u8 ? (float)static_cast<const uint8_t*>(a.ring_density)[src]
-                                                 : static_cast<const float*>(a.ring_density)[src];
+            a.out_density[i] = a.ring_storage == SVR_U8    ? (float)static_cast<const uint8_t*>(a.ring_density)[src]
+                               : a.ring_storage == SVR_U16 ? (float)static_cast<const uint16_t*>(a.ring_density)[src]
+                                                           : static_cast<const float*>(a.ring_density)[src];
         if (a.out_labels)  a.out_labels[i]  = a.ring_labels[src];
     }
 }
@@ -126,18 +166,39 @@ inline int grid_for(size_t n) {
 
 }  // namespace
 
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream) {
     const size_t n = (size_t)a.shape[0] * (size_t)a.shape[1] * (size_t)a.shape[2];
     if (n == 0) return hipSuccess;
+    // streaming path: element types already those of the ring, rows packed and cut on 16-voxel groups
+    const int des = (int)svr_dtype_size(a.ring_storage);
+    const bool d_ok = !a.src_density ||
+        (a.density_dtype == a.ring_storage && a.dstride[0] == des && aligned16(a.src_density) &&
+         a.dstride[1] % 16 == 0 && a.dstride[2] % 16 == 0);
+    const bool l_ok = !a.src_labels ||
+        ((a.labels_dtype == SVR_U32 || a.labels_dtype == SVR_I32) && a.lstride[0] == 4 && aligned16(a.src_labels) &&
+         a.lstride[1] % 16 == 0 && a.lstride[2] % 16 == 0);
+    const bool geo_ok = (a.shape[0] & 15) == 0 && (a.dst_off[0] & 15) == 0 && (a.ring[0] & 15) == 0 &&
+                        aligned16(a.ring_density) && aligned16(a.ring_labels) && n / 16 < 0x7fffffffu;
+    static const bool force_general = getenv("SVR_SCATTER_GENERAL") != nullptr;      // A/B measurements only
+    if (d_ok && l_ok && geo_ok && !force_general) {
+        const uint32_t gpr = (uint32_t)a.shape[0] / 16u, total = (uint32_t)(n / 16);
+        const dim3 grid((total + 255u) / 256u), block(256);
+        if (des == 1)      hipLaunchKernelGGL((scatter_rows16<1>), grid, block, 0, stream, a, gpr, total);
+        else if (des == 2) hipLaunchKernelGGL((scatter_rows16<2>), grid, block, 0, stream, a, gpr, total);
+        else               hipLaunchKernelGGL((scatter_rows16<4>), grid, block, 0, stream, a, gpr, total);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
-hipError_t svr_launch_gather(const void* ring_density, int ring_density_u8, const uint32_t* ring_labels, const int32_t ring[3],
+hipError_t svr_launch_gather(const void* ring_density, int ring_storage, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream) {
     GatherArgs a;
-    a.ring_density = ring_density; a.ring_density_u8 = ring_density_u8; a.ring_labels = ring_labels;
+    a.ring_density = ring_density; a.ring_storage = ring_storage; a.ring_labels = ring_labels;
     for (int i = 0; i < 3; ++i) { a.ring[i] = ring[i]; a.off[i] = off[i]; a.shape[i] = shape[i]; }
     a.out_density = out_density; a.out_labels = out_labels;
     const size_t n = (size_t)shape[0] * (size_t)shape[1] * (size_t)shape[2];

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "svr_internal.h"
 
@@ -55,8 +56,9 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         for (int a = 0; a < 3; ++a)
             SVR_REQUIRE(lods[l].ring_dims[a] >= 1 && lods[l].ring_dims[a] < (1 << 24),
                         "svr_create: ring extent must be in [1, 2^24)");
-        SVR_REQUIRE(lods[l].density_storage == SVR_F32 || lods[l].density_storage == SVR_U8,
-                    "svr_create: density_storage must be SVR_F32 or SVR_U8");
+        SVR_REQUIRE(lods[l].density_storage == SVR_F32 || lods[l].density_storage == SVR_U8 ||
+                    lods[l].density_storage == SVR_U16,
+                    "svr_create: density_storage must be SVR_F32, SVR_U8 or SVR_U16");
         SVR_REQUIRE(lods[l].density_storage == lods[0].density_storage,
                     "svr_create: all LODs must use the same density_storage");
     }
@@ -66,18 +68,20 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->render_stream = nullptr; c->upload_stream = nullptr; c->uploads_published = nullptr;
     c->have_published = false; c->colors_dev = nullptr; c->colors_cap = 0; c->material_set = false;
     c->variant = 0; c->slot_bytes = 0; c->next_slot = 0; c->ev_a = c->ev_b = nullptr;
-    c->render_done = nullptr; c->render_pending = false;
+    c->next_ticket = 1;
+    for (auto& t : c->tickets) t = nullptr;
     c->uploads_marker = nullptr; c->marker_set = false; c->dbg_dev = nullptr;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
+    c->density_storage = lods[0].density_storage;
     c->density_u8 = lods[0].density_storage == SVR_U8 ? 1 : 0;
+    c->staged_bytes = 0;
 
     auto fail = [&](int code) { svr_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->render_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->uploads_published, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->render_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->uploads_marker, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
         svr_set_error("svr_create: stream/event creation failed");
@@ -93,7 +97,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         c->lod_base_bytes[l] = total;                         // voxel offset of this LOD
         total += (L.voxels + 255) & ~(size_t)255;
     }
-    const size_t des = c->density_u8 ? 1 : sizeof(float);
+    const size_t des = svr_dtype_size(c->density_storage);
     c->density_all_bytes = total * des + 64;                 // + slack: 16-byte brick loads may overrun a row end
     // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
     if (hipMalloc((void**)&c->density_all, c->density_all_bytes) != hipSuccess ||
@@ -129,10 +133,12 @@ int svr_destroy(svr_ctx* c) {
         if (s.done) (void)hipEventDestroy(s.done);
     }
     if (c->colors_dev) (void)hipFree(c->colors_dev);
+    for (float* p : c->colors_retired) (void)hipFree(p);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto& t : c->tile_orders) if (t.dev) (void)hipFree(t.dev);
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
-    if (c->render_done) (void)hipEventDestroy(c->render_done);
+    for (auto& m : c->render_marks) if (m.done) (void)hipEventDestroy(m.done);
+    for (auto& t : c->tickets) if (t) (void)hipEventDestroy(t);
     if (c->uploads_marker) (void)hipEventDestroy(c->uploads_marker);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -163,25 +169,35 @@ int svr_get_lod_state(svr_ctx* c, int lod, svr_lod_state* st) {
 int svr_set_material(svr_ctx* c, const svr_material* m) {
     SVR_REQUIRE(c && m, "svr_set_material: null argument");
     SVR_REQUIRE(m->color_count >= 1 && m->colors, "svr_set_material: at least one colour is required");
+    SVR_REQUIRE(m->clipping_plane_count <= SVR_MAX_CLIP_PLANES, "svr_set_material: too many clipping planes");
+    SVR_REQUIRE(m->clipping_plane_count == 0 || m->clipping_planes, "svr_set_material: clipping_planes is null");
     DeviceGuard guard(c->device);
     const size_t ncol = (size_t)m->color_count * 4;
     const bool same_colors = c->material_set && c->colors_host.size() == ncol &&
                              memcmp(c->colors_host.data(), m->colors, ncol * sizeof(float)) == 0;
     c->material = *m;
     c->material.colors = nullptr;
+    c->material.clipping_planes = nullptr;
+    c->clip_host.assign(m->clipping_planes, m->clipping_planes + (size_t)m->clipping_plane_count * 4);
     if (same_colors) return SVR_OK;
     c->colors_host.assign(m->colors, m->colors + ncol);
-    if (m->color_count > c->colors_cap) {
-        if (c->colors_dev) { SVR_HIP_TRY(hipStreamSynchronize(c->render_stream)); (void)hipFree(c->colors_dev); c->colors_dev = nullptr; }
-        uint32_t cap = std::max<uint32_t>(256u, m->color_count);
-        if (hipMalloc((void**)&c->colors_dev, (size_t)cap * 4 * sizeof(float)) != hipSuccess) {
-            svr_set_error("svr_set_material: out of device memory"); return SVR_ERR_NOMEM;
-        }
-        c->colors_cap = cap;
+    // The colour table of renders still in flight must not change under them: every new table goes into a
+    // fresh device buffer (the old one is freed once the device has drained; tables are tiny and change
+    // rarely), so no device-wide synchronisation is needed here.
+    float* fresh = nullptr;
+    const uint32_t cap = std::max<uint32_t>(256u, m->color_count);
+    if (hipMalloc((void**)&fresh, (size_t)cap * 4 * sizeof(float)) != hipSuccess) {
+        svr_set_error("svr_set_material: out of device memory"); return SVR_ERR_NOMEM;
     }
-    // synchronous small copy: ordered before any later launch on any stream
-    SVR_HIP_TRY(hipDeviceSynchronize());
-    SVR_HIP_TRY(hipMemcpy(c->colors_dev, c->colors_host.data(), c->colors_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    SVR_HIP_TRY(hipMemcpy(fresh, c->colors_host.data(), c->colors_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (c->colors_dev) c->colors_retired.push_back(c->colors_dev);
+    if (c->colors_retired.size() > 32) {                 // bounded: drain once in a long while
+        SVR_HIP_TRY(hipDeviceSynchronize());
+        for (float* p : c->colors_retired) (void)hipFree(p);
+        c->colors_retired.clear();
+    }
+    c->colors_dev = fresh;
+    c->colors_cap = cap;
     c->material_set = true;
     return SVR_OK;
 }
@@ -211,7 +227,39 @@ static int check_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t
 // about to overwrite: order the upload stream behind it (the reference gets this
 // ordering from running everything on one queue).
 static int uploads_after_render(svr_ctx* c) {
-    if (c->render_pending.exchange(false)) SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->render_done, 0));
+    std::lock_guard<std::mutex> lock(c->marks_mu);
+    for (auto& m : c->render_marks)
+        if (m.pending) {
+            SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, m.done, 0));
+            m.pending = false;
+        }
+    return SVR_OK;
+}
+
+// Remember that stream `s` carries a render enqueued just now (one event per stream; a stream's later
+// render re-records its event, which then covers the earlier ones on that stream too).
+static int mark_render(svr_ctx* c, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(c->marks_mu);
+    svr_ctx::RenderMark* mark = nullptr;
+    for (auto& m : c->render_marks) if (m.stream == s) { mark = &m; break; }
+    if (!mark) {
+        if (c->render_marks.size() >= 64) {
+            // a caller cycling through many short-lived streams: recycle the oldest entry, after ordering the
+            // upload stream behind the render it still stands for
+            svr_ctx::RenderMark old = c->render_marks.front();
+            if (old.pending) SVR_HIP_TRY(hipStreamWaitEvent(c->upload_stream, old.done, 0));
+            c->render_marks.erase(c->render_marks.begin());
+            old.stream = s; old.pending = false;
+            c->render_marks.push_back(old);
+        } else {
+            svr_ctx::RenderMark m{ s, nullptr, false };
+            SVR_HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+            c->render_marks.push_back(m);
+        }
+        mark = &c->render_marks.back();
+    }
+    SVR_HIP_TRY(hipEventRecord(mark->done, s));
+    mark->pending = true;
     return SVR_OK;
 }
 
@@ -231,16 +279,41 @@ static int ensure_staging(svr_ctx* c) {
     return SVR_OK;
 }
 
-// copy rows [z0,z1) of a strided host block into a packed buffer (x fastest)
-static void pack_rows(const char* src, size_t es, const int64_t st[3], const int32_t shape[3], int z0, int z1, char* dst) {
+// Copy rows [r0, r1) of a strided host block into a packed buffer (x fastest); a row index is z * shape[1] + y.
+static void pack_row_range(const char* src, size_t es, const int64_t st[3], const int32_t shape[3],
+                           int64_t r0, int64_t r1, char* dst) {
     const size_t row = (size_t)shape[0] * es;
-    for (int z = z0; z < z1; ++z)
-        for (int y = 0; y < shape[1]; ++y) {
-            const char* s = src + (int64_t)z * st[2] + (int64_t)y * st[1];
-            if (st[0] == (int64_t)es) memcpy(dst, s, row);
-            else for (int x = 0; x < shape[0]; ++x) memcpy(dst + (size_t)x * es, s + (int64_t)x * st[0], es);
-            dst += row;
-        }
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t z = r / shape[1], y = r % shape[1];
+        const char* s = src + z * st[2] + y * st[1];
+        if (st[0] == (int64_t)es) memcpy(dst, s, row);
+        else for (int x = 0; x < shape[0]; ++x) memcpy(dst + (size_t)x * es, s + (int64_t)x * st[0], es);
+        dst += row;
+    }
+}
+
+// The host half of an upload is a gather of short rows (48 .. 528 voxels) out of a large strided array into the
+// pinned staging slot: one core moves ~6-10 GB/s that way, well under the PCIe rate, so the rows are dealt to a
+// few threads (contiguous row ranges; short-lived threads: a slot is tens of MiB, thread start-up is noise).
+static void pack_rows(const char* src, size_t es, const int64_t st[3], const int32_t shape[3],
+                      int64_t r0, int64_t r1, char* dst) {
+    const size_t row = (size_t)shape[0] * es;
+    const int64_t nrows = r1 - r0;
+    const size_t bytes = row * (size_t)nrows;
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes / ((size_t)2 << 20));
+    if (const char* e = getenv("SVR_PACK_THREADS")) nt = std::max(1, atoi(e));
+    if (nt <= 1 || nrows < 2 * nt) { pack_row_range(src, es, st, shape, r0, r1, dst); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)nt - 1);
+    const int64_t per = (nrows + nt - 1) / nt;
+    for (int t = 1; t < nt; ++t) {
+        const int64_t a = r0 + per * t, b = std::min(r1, a + per);
+        if (a >= b) break;
+        pool.emplace_back(pack_row_range, src, es, st, shape, a, b, dst + (size_t)(a - r0) * row);
+    }
+    pack_row_range(src, es, st, shape, r0, std::min(r1, r0 + per), dst);
+    for (auto& th : pool) th.join();
 }
 
 int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32_t shape[3],
@@ -253,42 +326,61 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     SVR_REQUIRE(!density || (des && density_strides), "svr_upload_region: bad density dtype/strides");
     SVR_REQUIRE(!labels || (les && labels_strides), "svr_upload_region: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
-    SVR_REQUIRE(!density || !c->density_u8 || density_dtype == SVR_U8,
-                "svr_upload_region: a context with SVR_U8 density storage only accepts uint8 density sources");
+    SVR_REQUIRE(!density || storage_accepts(c->density_storage, density_dtype),
+                "svr_upload_region: the context's integer density storage only accepts sources of that same dtype");
     if (shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return SVR_OK;
     DeviceGuard guard(c->device);
+    // one uploader at a time: the staging slots and the enqueue order on the upload stream are shared
+    // (the render thread may load synchronously while the streaming worker is inside this call)
+    std::lock_guard<std::mutex> upload_lock(c->upload_mu);
     rc = ensure_staging(c);
     if (rc) return rc;
     rc = uploads_after_render(c);
     if (rc) return rc;
     LodStorage& L = c->lod[lod];
-    const size_t plane_vox = (size_t)shape[0] * (size_t)shape[1];
-    // labels are placed after the density block, 16-byte aligned
-    const size_t per_z = plane_vox * (des + les) + 32;
-    SVR_REQUIRE(per_z <= c->slot_bytes, "svr_upload_region: one z-plane of the region exceeds the staging slot");
-    const int zs_max = (int)std::max<size_t>(1, (c->slot_bytes - 32) / (plane_vox * (des + les)));
-    for (int z0 = 0; z0 < shape[2]; z0 += zs_max) {
-        const int z1 = std::min(shape[2], z0 + zs_max);
+    // The region travels in blocks of whole rows, as many as fit a staging slot: whole z-planes when one
+    // fits (the scatter kernel then sees a box), else runs of rows inside one plane.  Labels are placed
+    // after the density block, 16-byte aligned.
+    const size_t row_bytes = (size_t)shape[0] * (des + les);
+    SVR_REQUIRE(row_bytes + 32 <= c->slot_bytes, "svr_upload_region: one row of the region exceeds the staging slot");
+    const int64_t rows_max = (int64_t)((c->slot_bytes - 32) / row_bytes);
+    const int64_t plane_rows = shape[1];
+    const int64_t total_rows = plane_rows * shape[2];
+    for (int64_t r0 = 0; r0 < total_rows;) {
+        int64_t nrows;
+        if (rows_max >= plane_rows && r0 % plane_rows == 0)
+            nrows = std::min(total_rows - r0, (rows_max / plane_rows) * plane_rows);        // whole planes
+        else
+            nrows = std::min(rows_max, plane_rows - r0 % plane_rows);                        // rows of one plane
+        const int64_t r1 = r0 + nrows;
         StagingSlot& S = c->slot[c->next_slot];
         c->next_slot = (c->next_slot + 1) % svr_ctx::kSlots;
         if (S.used) SVR_HIP_TRY(hipEventSynchronize(S.done));
-        const size_t dbytes = plane_vox * (size_t)(z1 - z0) * des;
+        const size_t dbytes = (size_t)shape[0] * (size_t)nrows * des;
         const size_t lofs = (dbytes + 15) & ~(size_t)15;
-        const size_t lbytes = plane_vox * (size_t)(z1 - z0) * les;
-        if (density) pack_rows(static_cast<const char*>(density), des, density_strides, shape, z0, z1, static_cast<char*>(S.host));
-        if (labels) pack_rows(static_cast<const char*>(labels), les, labels_strides, shape, z0, z1, static_cast<char*>(S.host) + lofs);
+        const size_t lbytes = (size_t)shape[0] * (size_t)nrows * les;
+        if (density) pack_rows(static_cast<const char*>(density), des, density_strides, shape, r0, r1, static_cast<char*>(S.host));
+        if (labels) pack_rows(static_cast<const char*>(labels), les, labels_strides, shape, r0, r1, static_cast<char*>(S.host) + lofs);
         SVR_HIP_TRY(hipMemcpyAsync(S.dev, S.host, lofs + lbytes, hipMemcpyHostToDevice, c->upload_stream));
+        // the staged block as a box of the ring
+        const int32_t z0 = (int32_t)(r0 / plane_rows), y0 = (int32_t)(r0 % plane_rows);
+        const int32_t bz = nrows >= plane_rows ? (int32_t)(nrows / plane_rows) : 1;
+        const int32_t by = nrows >= plane_rows ? shape[1] : (int32_t)nrows;
         ScatterArgs a;
         a.src_density = density ? S.dev : nullptr; a.density_dtype = density_dtype;
-        a.dstride[0] = (int64_t)des; a.dstride[1] = (int64_t)des * shape[0]; a.dstride[2] = (int64_t)des * shape[0] * shape[1];
+        a.dstride[0] = (int64_t)des; a.dstride[1] = (int64_t)des * shape[0]; a.dstride[2] = (int64_t)des * shape[0] * by;
         a.src_labels = labels ? static_cast<char*>(S.dev) + lofs : nullptr; a.labels_dtype = labels_dtype;
-        a.lstride[0] = (int64_t)les; a.lstride[1] = (int64_t)les * shape[0]; a.lstride[2] = (int64_t)les * shape[0] * shape[1];
-        a.ring_density = L.density; a.ring_labels = L.labels; a.ring_density_u8 = c->density_u8;
-        for (int i = 0; i < 3; ++i) { a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i]; }
-        a.dst_off[2] = dst_off[2] + z0; a.shape[2] = z1 - z0;
+        a.lstride[0] = (int64_t)les; a.lstride[1] = (int64_t)les * shape[0]; a.lstride[2] = (int64_t)les * shape[0] * by;
+        a.ring_density = L.density; a.ring_labels = L.labels; a.ring_storage = c->density_storage;
+        for (int i = 0; i < 3; ++i) a.ring[i] = L.ring[i];
+        a.dst_off[0] = dst_off[0]; a.dst_off[1] = dst_off[1] + y0; a.dst_off[2] = dst_off[2] + z0;
+        a.shape[0] = shape[0]; a.shape[1] = by; a.shape[2] = bz;
+        a.packed = 1;
         SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
         SVR_HIP_TRY(hipEventRecord(S.done, c->upload_stream));
         S.used = true;
+        c->staged_bytes += lofs + lbytes;
+        r0 = r1;
     }
     return SVR_OK;
 }
@@ -301,14 +393,15 @@ int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], cons
     SVR_REQUIRE(!density || (svr_dtype_size(density_dtype) && density_strides), "svr_upload_region_device: bad density dtype/strides");
     SVR_REQUIRE(!labels || (svr_dtype_size(labels_dtype) && labels_strides), "svr_upload_region_device: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
-    SVR_REQUIRE(!density || !c->density_u8 || density_dtype == SVR_U8,
-                "svr_upload_region_device: a context with SVR_U8 density storage only accepts uint8 density sources");
+    SVR_REQUIRE(!density || storage_accepts(c->density_storage, density_dtype),
+                "svr_upload_region_device: the context's integer density storage only accepts sources of that same dtype");
     DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> upload_lock(c->upload_mu);
     rc = uploads_after_render(c);
     if (rc) return rc;
     LodStorage& L = c->lod[lod];
     ScatterArgs a;
-    a.ring_density_u8 = c->density_u8;
+    a.ring_storage = c->density_storage; a.packed = 0;
     a.src_density = density; a.density_dtype = density_dtype;
     a.src_labels = labels; a.labels_dtype = labels_dtype;
     for (int i = 0; i < 3; ++i) {
@@ -348,6 +441,31 @@ int svr_uploads_pending(svr_ctx* c, int* pending) {
     return SVR_OK;
 }
 
+int svr_upload_ticket(svr_ctx* c, uint64_t* ticket) {
+    SVR_REQUIRE(c && ticket, "svr_upload_ticket: null argument");
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> upload_lock(c->upload_mu);      // behind whatever an uploader is enqueueing right now
+    std::lock_guard<std::mutex> lock(c->ticket_mu);
+    hipEvent_t& ev = c->tickets[c->next_ticket % svr_ctx::kTickets];
+    if (!ev) SVR_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SVR_HIP_TRY(hipEventRecord(ev, c->upload_stream));
+    *ticket = c->next_ticket++;
+    return SVR_OK;
+}
+
+int svr_ticket_pending(svr_ctx* c, uint64_t ticket, int* pending) {
+    SVR_REQUIRE(c && pending, "svr_ticket_pending: null argument");
+    *pending = 0;
+    std::lock_guard<std::mutex> lock(c->ticket_mu);
+    SVR_REQUIRE(ticket >= 1 && ticket < c->next_ticket, "svr_ticket_pending: no such ticket");
+    // a recycled slot holds a LATER event of the same stream: done there implies done here
+    DeviceGuard guard(c->device);
+    const hipError_t e = hipEventQuery(c->tickets[ticket % svr_ctx::kTickets]);
+    if (e == hipErrorNotReady) { *pending = 1; return SVR_OK; }
+    SVR_HIP_TRY(e);
+    return SVR_OK;
+}
+
 int svr_clear_lod(svr_ctx* c, int lod) {
     SVR_REQUIRE(c, "svr_clear_lod: null ctx");
     SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_clear_lod: lod out of range");
@@ -355,7 +473,8 @@ int svr_clear_lod(svr_ctx* c, int lod) {
     int rc = uploads_after_render(c);
     if (rc) return rc;
     LodStorage& L = c->lod[lod];
-    SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * (c->density_u8 ? 1 : sizeof(float)), c->upload_stream));
+    std::lock_guard<std::mutex> upload_lock(c->upload_mu);
+    SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * svr_dtype_size(c->density_storage), c->upload_stream));
     SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
     return SVR_OK;
 }
@@ -375,7 +494,7 @@ int svr_read_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t sha
         if (dtmp) (void)hipFree(dtmp);
         svr_set_error("svr_read_region: out of device memory"); return SVR_ERR_NOMEM;
     }
-    hipError_t e = svr_launch_gather(L.density, c->density_u8, L.labels, L.ring, off, shape, dtmp, ltmp, c->upload_stream);
+    hipError_t e = svr_launch_gather(L.density, c->density_storage, L.labels, L.ring, off, shape, dtmp, ltmp, c->upload_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->upload_stream);
     if (e == hipSuccess && dtmp) e = hipMemcpy(density_out, dtmp, n * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess && ltmp) e = hipMemcpy(labels_out, ltmp, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -444,6 +563,17 @@ static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, in
     return SVR_OK;
 }
 
+// Can the span kernel address this context's rings (32-bit byte offsets into one allocation, 24-bit row
+// index and row pitch)?  Otherwise every render takes the straightforward kernel's 64-bit addressing.
+static bool span_addressable(const svr_ctx* c) {
+    if (c->density_all_bytes >= ((size_t)1 << 32)) return false;
+    const uint64_t des = svr_dtype_size(c->density_storage);
+    for (int l = 0; l < c->num_lods; ++l)
+        if ((uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
+            (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
+    return true;
+}
+
 static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, MarchParams& P) {
     SVR_REQUIRE(c && cam && fr && out && out->rgba, "svr_render: null argument");
     SVR_REQUIRE(c->material_set, "svr_render: svr_set_material has not been called");
@@ -466,9 +596,15 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     const svr_material& m = c->material;
     P.clim0 = m.clim[0]; P.clim1 = m.clim[1]; P.gamma = m.gamma; P.opacity = m.opacity;
     P.lmip_threshold = m.lmip_threshold; P.lmip_fall_off = m.lmip_fall_off;
-    P.lmip_threshold_u8 = 256u;                                    // NaN or > 255: no byte reaches it
-    if (m.lmip_threshold <= 0.0f) P.lmip_threshold_u8 = 0u;
-    else if (m.lmip_threshold <= 255.0f) P.lmip_threshold_u8 = (uint32_t)ceilf(m.lmip_threshold);
+    {   // integer rings: "(f32)v >= threshold" as an integer compare; NaN or beyond the largest value: never
+        const float vmax = c->density_storage == SVR_U16 ? 65535.0f : 255.0f;
+        P.lmip_threshold_raw = (uint32_t)vmax + 1u;
+        if (m.lmip_threshold <= 0.0f) P.lmip_threshold_raw = 0u;
+        else if (m.lmip_threshold <= vmax) P.lmip_threshold_raw = (uint32_t)ceilf(m.lmip_threshold);
+    }
+    P.clip_count = m.clipping_plane_count; P.clip_all = m.clipping_mode_all;
+    for (uint32_t k = 0; k < m.clipping_plane_count; ++k)
+        for (int a = 0; a < 4; ++a) P.clip[k][a] = c->clip_host[4 * k + a];
     P.lmip_max_samples = m.lmip_max_samples; P.fog_density = m.fog_density;
     for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
@@ -501,7 +637,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     // kernel kind 0: span march, one wave per block; 2: span march, 2 x 2 waves per block; 1: simple (2 x 2)
     // (rings of 4 GiB or more fall back to the simple kernel's 64-bit addressing, see launch_nl)
-    P.block_waves_log2 = ((c->variant & 3) == 0 && c->density_all_bytes < ((size_t)1 << 32)) ? 0 : 1;
+    P.block_waves_log2 = ((c->variant & 3) == 0 && span_addressable(c)) ? 0 : 1;
     const int bw = (1 << P.block_waves_log2) << lw, bh = (1 << P.block_waves_log2) * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)
@@ -532,7 +668,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             ok = ok && (double)P.size[1] * Q.scale[1] * Q.ring[1] < 16777216.0;      // row index < 2^24
             P.lod_pow2[l] = ok ? 1 : 0;
         }
-        const uint32_t des = c->density_u8 ? 1u : 4u;
+        const uint32_t des = (uint32_t)svr_dtype_size(c->density_storage);
         Q.rx4 = Q.ring[0] * des;
         Q.base_bytes = (uint32_t)(c->lod_base_bytes[l] * des);
         for (int a = 0; a < 3; ++a) Q.ss[a] = P.size[a] * Q.scale[a];          // one IEEE multiply, as the kernel did
@@ -546,8 +682,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         }
     }
     P.density_all = c->density_all;
-    P.density_all_bytes = c->density_all_bytes < ((size_t)1 << 32) ? (uint32_t)c->density_all_bytes : 0u;
-    P.density_u8 = c->density_u8;
+    P.density_all_bytes = span_addressable(c) ? (uint32_t)c->density_all_bytes : 0u;
+    P.density_esh = c->density_storage == SVR_U8 ? 0 : (c->density_storage == SVR_U16 ? 1 : 2);
     return SVR_OK;
 }
 
@@ -561,9 +697,7 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
-    SVR_HIP_TRY(hipEventRecord(c->render_done, s));
-    c->render_pending = true;
-    return SVR_OK;
+    return mark_render(c, s);
 }
 
 int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out,
@@ -578,6 +712,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
     SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
     for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
+    { const int rcm = mark_render(c, s); if (rcm) return rcm; }
     SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
     float ms = 0.f;
     SVR_HIP_TRY(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));

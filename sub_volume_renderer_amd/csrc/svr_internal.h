@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,7 +43,7 @@ struct MarchParams {
     // u_material
     float clim0, clim1, gamma, opacity;
     float lmip_threshold, lmip_fall_off;
-    uint32_t lmip_threshold_u8;    // smallest byte b with (float)b >= lmip_threshold (256: none)
+    uint32_t lmip_threshold_raw;   // integer rings: smallest value v with (float)v >= lmip_threshold (max + 1: none)
     int32_t lmip_max_samples;
     float fog_density;
     float fog_color[3];
@@ -50,6 +51,10 @@ struct MarchParams {
     const float* colors;       // device, color_count x vec4
     int32_t colorspace_srgb;
     int32_t num_lods;
+    // Material.clipping_planes (pygfx.clipping_planes.wgsl, included at fs_main.wgsl:8)
+    uint32_t clip_count;
+    int32_t  clip_all;
+    float    clip[SVR_MAX_CLIP_PLANES][4];
     // outputs (device)
     float*    rgba;
     float*    depth;
@@ -62,7 +67,7 @@ struct MarchParams {
     // (32-bit byte offsets, hardware range check) addresses every LOD
     const void* density_all;
     uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
-    int32_t  density_u8;           // 1: density rings hold bytes (svr_lod_desc::density_storage)
+    int32_t  density_esh;          // log2 of the density element size: 0 u8, 1 u16, 2 f32 (svr_lod_desc::density_storage)
     // block -> tile mapping
     int32_t tiles_x, tiles_y;
     int32_t tile_log2w;            // wave tile = (1 << tile_log2w) x (64 >> tile_log2w) pixels
@@ -100,7 +105,9 @@ struct svr_ctx {
     int num_lods;
     LodStorage lod[SVR_MAX_LODS];
     void*     density_all;           // one allocation, LOD rings at 256-byte aligned offsets
-    int       density_u8;            // ring element type: 0 f32, 1 u8
+    int       density_storage;       // ring element type: SVR_F32 (reference layout), SVR_U8 or SVR_U16
+    int       density_u8;            // density_storage == SVR_U8
+    uint64_t  staged_bytes;          // bytes sent through the pinned staging slots so far (diagnostics)
     uint32_t* labels_all;
     size_t    density_all_bytes;
     size_t    lod_base_bytes[SVR_MAX_LODS];
@@ -112,6 +119,7 @@ struct svr_ctx {
     svr_material material;
     std::vector<float> colors_host;
     float* colors_dev;
+    std::vector<float*> colors_retired;   // tables replaced while renders may still read them
     uint32_t colors_cap;
     bool material_set;
     int variant;
@@ -121,14 +129,24 @@ struct svr_ctx {
     StagingSlot slot[kSlots];
     int next_slot;
     hipEvent_t ev_a, ev_b;           // timing
-    hipEvent_t render_done;          // recorded after the last enqueued render
-    std::atomic<bool> render_pending;
+    // One event per stream that has carried a render: uploads must wait for EVERY render still in flight
+    // (frames are kept in flight on several streams), not only for the most recently enqueued one.
+    struct RenderMark { hipStream_t stream; hipEvent_t done; bool pending; };
+    std::vector<RenderMark> render_marks;
+    std::mutex marks_mu;             // render thread records, upload thread waits
+    std::mutex upload_mu;            // the staging slots and the upload stream's enqueue order: one uploader at a time
+    std::vector<float> clip_host;    // clipping planes (abcd) of the current material
     uint32_t*  dbg_dev;              // 8 diagnostic counters (instrumented renders)
     // block -> tile tables (one per frame tiling and policy; entries are never rewritten)
     struct TileOrder { int tiles_x, tiles_y, mode; uint32_t* dev; };
     std::vector<TileOrder> tile_orders;
     hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
     std::atomic<bool> marker_set;
+    // svr_upload_ticket / svr_ticket_pending: ticket t lives in tickets[t % kTickets]
+    static constexpr int kTickets = 64;
+    hipEvent_t tickets[kTickets];
+    uint64_t   next_ticket;          // next ticket to hand out (first is 1)
+    std::mutex ticket_mu;
 };
 
 // error plumbing -------------------------------------------------------------
@@ -151,13 +169,14 @@ struct ScatterArgs {
     const void* src_density; int density_dtype; int64_t dstride[3];   // bytes per x,y,z step
     const void* src_labels;  int labels_dtype;  int64_t lstride[3];
     void* ring_density; uint32_t* ring_labels;
-    int32_t ring_density_u8;
+    int32_t ring_storage;          // svr_dtype of the density ring: SVR_U8 / SVR_U16 / SVR_F32
+    int32_t packed;                // the source is a staged block (x stride = element size, rows back to back)
     int32_t ring[3];
     int32_t dst_off[3];
     int32_t shape[3];
 };
 hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
-hipError_t svr_launch_gather(const void* ring_density, int ring_density_u8, const uint32_t* ring_labels, const int32_t ring[3],
+hipError_t svr_launch_gather(const void* ring_density, int ring_storage, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream);
 hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,
@@ -166,3 +185,5 @@ hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w,
 hipError_t svr_launch_pool2x(const void* src, void* dst, const int32_t dims[3], int dtype, int mode, hipStream_t stream);
 
 size_t svr_dtype_size(int dtype);
+// integer rings hold the source values themselves: only sources of that very dtype may be uploaded
+inline bool storage_accepts(int storage, int src_dtype) { return storage == SVR_F32 || src_dtype == storage; }

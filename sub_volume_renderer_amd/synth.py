@@ -73,6 +73,47 @@ def _pool(dens, lab, xp):
     return d, l
 
 
+_host_lib = None
+
+
+def host_lib():
+    """``libsvr_synth.so`` (csrc/synth_host.c): the same closed form, fused and multi-threaded; ``None`` when
+    it has not been built (``__graft_entry__.build_synth``) or ``SVR_SYNTH_NUMPY`` is set."""
+    global _host_lib
+    if _host_lib is None:
+        import ctypes as C
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvr_synth.so")
+        if os.environ.get("SVR_SYNTH_NUMPY") or not os.path.exists(path):
+            _host_lib = False
+        else:
+            lib = C.CDLL(path)
+            lib.svr_synth_block.restype = C.c_int
+            lib.svr_synth_block.argtypes = [C.c_int64, C.c_int, C.c_int64 * 3, C.c_int64 * 3, C.c_int64, C.c_int64 * 3,
+                                            C.c_void_p, C.c_void_p, C.c_int]
+            _host_lib = lib
+    return _host_lib or None
+
+
+def block_host(n: int, lod: int, off, shape, n_labels: int = 4096, nthreads: int = 0, want=(True, True)):
+    """``block`` through the fused host generator: (uint8 | None, uint32 | None) numpy arrays."""
+    import ctypes as C
+
+    lib = host_lib()
+    if lib is None:
+        raise RuntimeError("libsvr_synth.so has not been built")
+    I3 = C.c_int64 * 3
+    dens = np.empty(tuple(shape), np.uint8) if want[0] else None
+    lab = np.empty(tuple(shape), np.uint32) if want[1] else None
+    rc = lib.svr_synth_block(n, lod, I3(*[int(v) for v in off]), I3(*[int(v) for v in shape]), int(n_labels),
+                             I3(*_periods(n)), dens.ctypes.data if want[0] else None,
+                             lab.ctypes.data if want[1] else None, int(nthreads))
+    if rc != 0:
+        raise ValueError("svr_synth_block: argument out of range")
+    return dens, lab
+
+
 def block(n: int, lod: int, off, shape, n_labels: int = 4096, xp=np, device=None):
     """Block [off, off+shape) of LOD ``lod`` (extent n >> lod) as (uint8, uint32) arrays.
 
@@ -118,7 +159,19 @@ class LazyLod:
         self.dtype = np.dtype(np.uint32 if labels else np.uint8)
 
     def __getitem__(self, slices):
+        import time
+
         off = [s.start or 0 for s in slices]
         shape = [(s.stop if s.stop is not None else dim) - o for s, o, dim in zip(slices, off, self.shape)]
-        d, l = block(self.n, self.lod, off, shape, self.n_labels)
-        return l if self.labels else d
+        t = time.perf_counter()
+        if host_lib() is not None:
+            d, l = block_host(self.n, self.lod, off, shape, self.n_labels, want=(not self.labels, self.labels))
+        else:
+            d, l = block(self.n, self.lod, off, shape, self.n_labels)
+        out = l if self.labels else d
+        LazyLod.read_seconds += time.perf_counter() - t          # the "store read" share of a streaming run
+        LazyLod.read_bytes += out.nbytes
+        return out
+
+    read_seconds = 0.0
+    read_bytes = 0

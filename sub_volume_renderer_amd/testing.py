@@ -70,8 +70,15 @@ class BuiltScene:
 
 def build(spec: SceneSpec, device: int | None = None) -> BuiltScene:
     """Product side: a ``SubVolume`` with the spec's loads applied (needs the GPU)."""
+    # keys that are constructor arguments in the reference vs properties inherited from pygfx's Material /
+    # added here (set after construction, as a caller of the reference would)
+    later = ("clipping_planes", "clipping_mode", "render_mode")
+    material = SubVolumeMaterial(**{k: v for k, v in spec.material.items() if k not in later})
+    for k in later:
+        if k in spec.material:
+            setattr(material, k, spec.material[k])
     vol = SubVolume(
-        SubVolumeMaterial(**spec.material),
+        material,
         data_segmentation_pairs=list(spec.pairs),
         buffer_shape_in_chunks=list(spec.ring_shapes),
         chunk_shape_in_pixels=list(spec.chunk_shapes),

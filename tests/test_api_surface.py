@@ -33,7 +33,8 @@ def test_header_symbols_are_all_bound_and_exported():
 
 def test_abi_version_and_struct_sizes():
     lib = _native.lib()
-    assert lib.svr_abi_version() == 3
+    header = open(os.path.join(ROOT, "include", "svr.h")).read()
+    assert lib.svr_abi_version() == int(re.search(r"#define SVR_ABI_VERSION (\d+)", header).group(1))
     assert ctypes.sizeof(_native.LodState) == 36            # 3xi4 + 3xi4 + 3xf4 (_wrapping_buffer.py:15-19)
     assert ctypes.sizeof(_native.Camera) == 6 * 64 + 12
     assert ctypes.sizeof(_native.Frame) == 32

@@ -153,8 +153,13 @@ def test_one_rank_rccl_pipeline_equals_single_gpu_frame():
     import subprocess
     import sys
 
+    import socket
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    with socket.socket() as sock:                        # a port nobody holds right now (no fixed rendezvous port)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--check",
                           "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--modes", "full",
                           "--volume-n", "256", "--width", "640", "--height", "360"],

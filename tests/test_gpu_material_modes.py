@@ -1,0 +1,92 @@
+"""GPU: the material features beside the plain LMIP uniforms — clipping planes (fs_main.wgsl:8), the MIP
+render mode (FUTURE.md:97-120) — and uint16 ring storage, each against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from oracle import lmip
+from sub_volume_renderer_amd import testing
+
+from test_gpu_render import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["ANY", "ALL"])
+@pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
+def test_clipping_planes_match_oracle(mode, inside):
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside, threshold=0.4)
+    spec.material.update(clipping_planes=[(1.0, 0.2, 0.0, 30.0), (0.0, -1.0, 0.3, -50.0)], clipping_mode=mode)
+    scene = testing.build(spec)
+    _, ref, rep = check(scene)
+    plain = lmip.render_spec(testing.synthetic_spec(64, 160, 96, inside=inside, threshold=0.4))
+    assert (ref.flags != plain.flags).sum() > 50              # the planes really remove rays
+    # planes can be changed and removed again between draws
+    scene.volume.material.clipping_planes = []
+    scene.spec.material.update(clipping_planes=[])
+    _, ref2, _ = check(scene)
+    np.testing.assert_array_equal(ref2.flags, plain.flags)
+
+
+def test_eight_clipping_planes_and_limit():
+    spec = testing.synthetic_spec(64, 96, 64, threshold=0.4)
+    planes = [(np.cos(k), np.sin(k), 0.1 * k, -40.0 + 3 * k) for k in range(8)]
+    spec.material.update(clipping_planes=planes, clipping_mode="ANY")
+    check(testing.build(spec), want_hits=False)
+    with pytest.raises(ValueError):
+        testing.build(spec).volume.material.clipping_planes = planes + [(1, 0, 0, 0)]
+
+
+@pytest.mark.parametrize("storage", ["native", "float32"])
+@pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
+def test_mip_mode_matches_oracle(inside, storage):
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside)
+    spec.ring_storage = storage
+    spec.material.update(render_mode="mip")
+    scene = testing.build(spec)
+    _, ref, rep = check(scene)
+    assert rep["n_miss"] == 0 and rep["n_hit"] > 1000
+    # back to LMIP: the lmip_* properties were left alone
+    scene.volume.material.render_mode = "lmip"
+    scene.spec.material.update(render_mode="lmip")
+    _, ref2, rep2 = check(scene)
+    assert rep2["n_miss"] > 0 and rep2["total_steps"] < rep["total_steps"]
+
+
+@pytest.mark.parametrize("full", [False, True], ids=["lmip", "full"])
+@pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
+def test_uint16_sources_get_uint16_rings_with_identical_results(inside, full):
+    """Common microscopy dtype: u16 values are exact in f32, so byte-for-byte the same frame as the reference's
+    r32float layout at half the memory."""
+    from sub_volume_renderer_amd import synth
+
+    pairs = []
+    for k in range(3):
+        d, l = synth.volume(64, k)
+        pairs.append((d.astype(np.uint16) * 257, l))           # 0 .. 65535
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside, full=full, pairs=pairs)
+    if not full:
+        spec.material.update(lmip_threshold=0.5 * 65535, clim=(0.0, 65535.0))
+    scene = testing.build(spec)
+    assert scene.volume._rings.density_storage == "uint16"
+    res, ref, rep = check(scene, want_hits=not full)
+    spec.ring_storage = "float32"
+    scene32 = testing.build(spec)
+    assert scene32.volume._rings.density_storage == "float32"
+    import torch
+
+    r32 = scene32.volume.render(scene32.camera, scene32.width, scene32.height, count_steps=True)
+    torch.cuda.synchronize()
+    for plane in ("rgba", "depth", "label", "flags", "steps"):
+        assert torch.equal(getattr(res, plane), getattr(r32, plane)), plane
+
+
+def test_uint16_threshold_edges():
+    """Integer pre-check against ceil(threshold): thresholds at, just above and beyond the value range."""
+    d = np.full((16, 16, 16), 65535, np.uint16)
+    d[::2] = 40000
+    seg = np.ones(d.shape, np.uint32)
+    for thr in (65535.0, 65534.5, 65535.5, 40000.0, 40000.25, 0.0, -1.0, float("inf"), float("nan")):
+        spec = testing.synthetic_spec(16, 48, 32, pairs=[(d, seg)], chunk_shapes=[(4, 4, 4)], ring_shapes=[(4, 4, 4)])
+        spec.material.update(lmip_threshold=thr, clim=(0.0, 65535.0))
+        spec.centers = [((7.5, 7.5, 7.5), [(16, 16, 16)])]
+        check(testing.build(spec), want_hits=False)

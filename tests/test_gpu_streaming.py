@@ -1,0 +1,298 @@
+"""GPU: the streaming front-end around the march — asynchronous ring reloads with frames in flight on several
+streams, failure of a backing array part-way, mixing blocking and asynchronous loads, upload order, tensorstore-
+shaped sources, and the limits of one upload call."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import lmip
+from sub_volume_renderer_amd import Roi, WrappingBuffer, testing
+
+pytestmark = pytest.mark.gpu
+RGBA_TOL = 1e-4
+
+
+def _published_rings(vol, orac):
+    """Oracle ring contents with the ROI the PRODUCT has published right now."""
+    rings = lmip.rings_of(orac)
+    for ring, b in zip(rings, vol.wrapping_buffers):
+        u = b.uniform_buffer.data
+        ring["offset"] = tuple(int(v) for v in u["current_logical_offset_in_pixels"])
+        ring["shape"] = tuple(int(v) for v in u["current_logical_shape_in_pixels"])
+    return rings
+
+
+def _assert_frame(res, ref, what):
+    rep = testing.compare(res, ref)
+    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], (what, rep)
+    assert rep["rgba_max_rel"] <= RGBA_TOL and rep["depth_max_abs"] <= 1e-4, (what, rep)
+
+
+def test_frames_in_flight_on_two_streams_never_tear_under_async_reloads():
+    """Renders alternate between two HIP streams while center_on_position(asynchronous=True) rewrites ring
+    slots: an upload must wait for EVERY render still in flight, not only for the latest one.  Each frame is
+    compared with the oracle for the ROI state that was published when it was enqueued."""
+    import torch
+
+    spec = testing.synthetic_spec(96, 256, 160, inside=True, chunk_shapes=[(8, 8, 16), (4, 4, 16), (2, 2, 16)],
+                                  ring_shapes=[(5, 5, 3), (8, 8, 3), (8, 8, 2)])
+    scene = testing.build(spec)
+    vol = scene.volume
+    orac = lmip.oracle_volume(spec)
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [vol._outputs(spec.height, spec.width, True), None]
+    vol._out_cache = {}
+    outs[1] = vol._outputs(spec.height, spec.width, True)
+    pending = []
+    for k in range(1, 13):
+        p = eye + d * 5.0 * k
+        spec.cam_position = tuple(p)
+        spec.cam_target = tuple(p + d)
+        cam = spec.camera()
+        slot = k & 1
+        if len(pending) == 2:                              # the frame that used this output buffer two frames ago
+            res, rings, mats, s = pending.pop(0)
+            s.synchronize()
+            ref = lmip.render(rings, mats, orac.volume_dimensions_shader, spec.material, spec.width, spec.height)
+            _assert_frame(res, ref, ("frame", k - 2))
+        with torch.cuda.stream(streams[slot]):
+            res = vol.render(cam, spec.width, spec.height, count_steps=True, out=outs[slot])
+        # what this frame must show: the textures BEFORE the next move, the ROIs published at its prepare()
+        rings = [dict(r, density=r["density"].copy(), labels=r["labels"].copy()) for r in _published_rings(vol, orac)]
+        pending.append((res, rings, spec.matrices(), streams[slot]))
+        vol.center_on_position(tuple(p), asynchronous=True)   # overwrites slots while both frames may still run
+        orac.center_on_position(tuple(p))
+    for res, rings, mats, s in pending:
+        s.synchronize()
+        _assert_frame(res, lmip.render(rings, mats, orac.volume_dimensions_shader, spec.material, spec.width, spec.height), "tail")
+    vol.poll_uploads(wait=True)
+    for b, ob in zip(vol.wrapping_buffers, orac.wrapping_buffers):
+        np.testing.assert_array_equal(b.texture.data, ob.texture)
+
+
+class _FailingArray:
+    """numpy-backed array whose reads fail while `armed` holds a positive count-down."""
+
+    def __init__(self, a):
+        self.a, self.shape, self.ndim, self.dtype, self.fail_after = a, a.shape, a.ndim, a.dtype, None
+
+    def __getitem__(self, sl):
+        if self.fail_after is not None:
+            self.fail_after -= 1
+            if self.fail_after < 0:
+                raise IOError("backing store went away")
+        return self.a[sl]
+
+
+def test_failed_asynchronous_load_keeps_the_shrunk_window_and_recovers():
+    import torch
+
+    spec = testing.synthetic_spec(64, 96, 64, inside=True)
+    flaky = _FailingArray(spec.pairs[0][0])
+    spec.pairs = [(flaky, spec.pairs[0][1])] + list(spec.pairs[1:])
+    scene = testing.build(spec)
+    vol = scene.volume
+    plain = testing.synthetic_spec(64, 96, 64, inside=True)
+    orac = lmip.oracle_volume(plain)
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    p = eye + d * 14.0
+    before = [b._current_logical_roi_in_pixels for b in vol.wrapping_buffers]
+    flaky.fail_after = 1                                     # the second piece of LOD 0 raises on the worker thread
+    vol.center_on_position(tuple(p), asynchronous=True)
+    with pytest.raises(IOError):
+        vol.poll_uploads(wait=True)
+    b0 = vol.wrapping_buffers[0]
+    assert b0._pending_async is None
+    shrunk = b0._current_logical_roi_in_pixels               # old & new, NOT the new ROI
+    assert shrunk is None or before[0].contains(shrunk)
+    assert vol.poll_uploads(wait=True) is True                # raised once, nothing left in flight
+    # the frame still equals the oracle for the published state: old textures where the shrunk window maps them
+    res = vol.render(scene.camera, spec.width, spec.height, count_steps=True)
+    torch.cuda.synchronize()
+    rings = _published_rings(vol, orac)                       # oracle textures = before the move
+    if shrunk is not None:
+        _assert_frame(res, lmip.render(rings, spec.matrices(), orac.volume_dimensions_shader, plain.material,
+                                       spec.width, spec.height), "after failure")
+    # the store comes back: the next request re-plans everything that is missing
+    flaky.fail_after = None
+    vol.center_on_position(tuple(p), asynchronous=True)
+    vol.poll_uploads(wait=True)
+    orac.center_on_position(tuple(p))
+    for b, ob in zip(vol.wrapping_buffers, orac.wrapping_buffers):
+        got = b._current_logical_roi_in_pixels
+        assert (tuple(got.offset), tuple(got.shape)) == ob.current_logical_roi_in_pixels
+        roi = Roi(*ob.current_logical_roi_in_pixels).intersect(Roi((0, 0, 0), ob.backing_data.shape))
+        ring = np.array(ob.texture.shape)
+        # every voxel of the window is the right one: buf[pos % ring] == data[pos]
+        zz, yy, xx = [np.arange(o, o + s) for o, s in zip(roi.offset, roi.shape)]
+        tex = b.texture.data
+        np.testing.assert_array_equal(tex[np.ix_(zz % ring[0], yy % ring[1], xx % ring[2])],
+                                      np.asarray(ob.backing_data)[np.ix_(zz, yy, xx)].astype(np.float32))
+
+
+def test_latest_request_wins_and_blocking_load_waits_for_the_worker():
+    spec = testing.synthetic_spec(64, 96, 64, inside=True)
+    gate = threading.Event()
+
+    class Slow(_FailingArray):
+        def __getitem__(self, sl):
+            gate.wait(5.0)
+            return self.a[sl]
+
+    spec.pairs = [(Slow(spec.pairs[0][0]), spec.pairs[0][1])] + list(spec.pairs[1:])
+    gate.set()
+    scene = testing.build(spec)
+    vol = scene.volume
+    orac = lmip.oracle_volume(testing.synthetic_spec(64, 96, 64, inside=True))
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    gate.clear()                                             # the worker blocks inside the first read
+    vol.center_on_position(tuple(eye + d * 6.0), asynchronous=True)
+    vol.center_on_position(tuple(eye + d * 12.0), asynchronous=True)      # remembered
+    vol.center_on_position(tuple(eye + d * 18.0), asynchronous=True)      # replaces the remembered one
+    assert vol.wrapping_buffers[0]._wanted_roi is not None
+    gate.set()
+    vol.poll_uploads(wait=True)
+    orac.center_on_position(tuple(eye + d * 6.0))
+    orac.center_on_position(tuple(eye + d * 18.0))           # 12.0 was dropped: the last camera move is what counts
+    for b, ob in zip(vol.wrapping_buffers, orac.wrapping_buffers):
+        got = b._current_logical_roi_in_pixels
+        assert (tuple(got.offset), tuple(got.shape)) == ob.current_logical_roi_in_pixels
+    # a blocking call while the worker is busy waits for it instead of interleaving with it
+    gate.clear()
+    vol.center_on_position(tuple(eye + d * 24.0), asynchronous=True)
+    threading.Timer(0.2, gate.set).start()
+    vol.center_on_position(tuple(eye + d * 30.0))            # blocking
+    orac.center_on_position(tuple(eye + d * 24.0))
+    orac.center_on_position(tuple(eye + d * 30.0))
+    for b, ob in zip(vol.wrapping_buffers, orac.wrapping_buffers):
+        assert b._pending_async is None
+        got = b._current_logical_roi_in_pixels
+        assert (tuple(got.offset), tuple(got.shape)) == ob.current_logical_roi_in_pixels
+        np.testing.assert_array_equal(b.texture.data, ob.texture)
+
+
+def test_uploads_go_coarse_level_first_and_near_pieces_first():
+    spec = testing.synthetic_spec(64, 96, 64, inside=True)
+    order = []
+
+    class Spy(_FailingArray):
+        def __init__(self, a, lod):
+            super().__init__(a)
+            self.lod = lod
+
+        def __getitem__(self, sl):
+            order.append((self.lod, tuple(s.start for s in sl)))
+            return self.a[sl]
+
+    spec.pairs = [(Spy(d, k), l) for k, (d, l) in enumerate(spec.pairs)]
+    scene = testing.build(spec)
+    vol = scene.volume
+    del order[:]
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    p = eye + d * 20.0
+    vol.center_on_position(tuple(p), asynchronous=True)
+    vol.poll_uploads(wait=True)
+    lods = [lod for lod, _ in order]
+    assert len(set(lods)) >= 2 and lods == sorted(lods, reverse=True)       # low res first (FUTURE.md:86-95)
+    focus = (vol.world.inverse_matrix @ np.array([*p, 1.0]))[:3][::-1]
+    for lod in set(lods):
+        b = vol.wrapping_buffers[lod]
+        starts = [np.array(s) for l, s in order if l == lod]
+        # piece order is by distance of the piece CENTRE; its begin corner is within one piece of that
+        dist = [np.linalg.norm(s - focus * np.array(b.scale_factor)) for s in starts]
+        assert len(dist) < 2 or dist[0] <= max(dist)
+
+
+class FakeTensorStore:
+    """The two things ``load_into_buffer`` uses of a tensorstore array (_wrapping_buffer.py:307-322):
+    ``.origin`` (index of the first element) and slices that are lazy until ``.read().result()``."""
+
+    def __init__(self, a, origin):
+        self._a, self.origin, self.shape, self.ndim, self.dtype = a, tuple(origin), a.shape, a.ndim, a.dtype
+        self.reads = 0
+
+    def __getitem__(self, sl):
+        outer = self
+        # tensorstore indexes in its own index space: [origin, origin + shape)
+        local = tuple(slice(s.start - o, s.stop - o) for s, o in zip(sl, self.origin))
+        for s, n in zip(local, self.shape):
+            assert 0 <= s.start <= s.stop <= n, "read outside the store's domain"
+
+        class Lazy:
+            def read(self):
+                class Future:
+                    def result(self_inner):
+                        outer.reads += 1
+                        return outer._a[local]
+                return Future()
+        return Lazy()
+
+
+def test_tensorstore_shaped_sources_with_nonzero_origin():
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 255, (32, 32, 32), dtype=np.uint8)
+    seg = rng.integers(0, 2 ** 32, data.shape, dtype=np.uint32)
+    ts_d, ts_s = FakeTensorStore(data, (100, -20, 7)), FakeTensorStore(seg, (100, -20, 7))
+    buf = WrappingBuffer(ts_d, ts_s, (3, 3, 3), (8, 8, 8))
+    plain = WrappingBuffer(data, seg, (3, 3, 3), (8, 8, 8))
+    for roi in (Roi((0, 0, 0), (16, 16, 16)), Roi((8, 12, 4), (16, 16, 16)), Roi((20, 20, 20), (16, 16, 16))):
+        buf.load_logical_roi(roi)
+        plain.load_logical_roi(roi)
+        assert buf._current_logical_roi_in_pixels == plain._current_logical_roi_in_pixels
+        np.testing.assert_array_equal(buf.texture.data, plain.texture.data)
+        np.testing.assert_array_equal(buf.segmentations_texture.data, plain.segmentations_texture.data)
+    assert ts_d.reads > 0 and ts_s.reads == ts_d.reads
+
+
+def test_one_plane_larger_than_a_staging_slot_is_split_by_rows():
+    """The reference accepts any block size; a z-plane of 8192 x 2048 voxels (u8 + u32 = 84 MB) exceeds the
+    48 MiB staging slot and travels as runs of rows."""
+    rng = np.random.default_rng(2)
+    data = rng.integers(0, 255, (2, 2048, 8192), dtype=np.uint8)
+    seg = rng.integers(0, 2 ** 32, data.shape, dtype=np.uint32)
+    buf = WrappingBuffer(data, seg, (2, 2, 2), (1, 1024, 4096))
+    buf.load_logical_roi(Roi((0, 0, 0), (2, 2048, 8192)))
+    d, l = buf.read_ring(Roi((0, 0, 0), (2, 2048, 8192)))
+    np.testing.assert_array_equal(d, data.astype(np.float32))
+    np.testing.assert_array_equal(l, seg)
+
+
+def test_rings_beyond_the_span_kernels_24_bit_row_index_render_exactly():
+    """ring_y * ring_z >= 2^24 (64 x 8192 x 4096 voxels, 2 GiB of bytes): the span kernel's 24-bit row
+    arithmetic cannot address it, so the draw takes the straightforward kernel — same pixels as the oracle."""
+    import torch
+
+    from sub_volume_renderer_amd import SubVolume, SubVolumeMaterial
+    from sub_volume_renderer_amd._transform import PerspectiveCamera
+
+    n = (48, 40, 64)                                          # the data is small; the RING is huge
+    rng = np.random.default_rng(4)
+    data = rng.integers(0, 255, n, dtype=np.uint8)
+    seg = rng.integers(0, 1000, n, dtype=np.uint32)
+    spec = testing.synthetic_spec(64, 96, 64, pairs=[(data, seg)], chunk_shapes=[(8, 8, 64)], ring_shapes=[(512, 1024, 1)],
+                                  threshold=0.6)
+    spec.centers = [((31.5, 19.5, 23.5), [n])]
+    c = np.array([31.5, 19.5, 23.5])
+    spec.cam_position = tuple(c + np.array([-90.0, 40.0, 55.0]))
+    spec.cam_target = tuple(c)
+    scene = testing.build(spec)
+    res = scene.volume.render(scene.camera, spec.width, spec.height, count_steps=True)
+    torch.cuda.synchronize()
+    # the oracle would need the 2 GiB ring as f32: feed it an equivalent small ring instead (same ROI, the
+    # window does not wrap, so slot == voxel index in both)
+    small = testing.synthetic_spec(64, 96, 64, pairs=[(data, seg)], chunk_shapes=[(8, 8, 64)], ring_shapes=[(6, 5, 1)],
+                                   threshold=0.6)
+    small.centers, small.cam_position, small.cam_target = spec.centers, spec.cam_position, spec.cam_target
+    ref = lmip.render_spec(small)
+    _assert_frame(res, ref, "huge ring")
+    assert (ref.flags == 2).sum() > 50

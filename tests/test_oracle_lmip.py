@@ -134,3 +134,78 @@ def test_pick_word_layout_and_restatements_agree():
     c = lmip.render_spec(spec, nthreads=2, pick_id=0xFFFFFFF)
     assert np.all((c.pick[hit] & np.uint64(0xFFFFF)) == np.uint64(0xFFFFF))
     np.testing.assert_array_equal(c.pick[hit] >> np.uint64(20), w >> np.uint64(20))
+
+
+# ---- clipping planes (fs_main.wgsl:8: pygfx.clipping_planes.wgsl, restated — assumption A6) -----------------------
+def _back_face_world_x(spec):
+    """World x of the point where each pixel's ray leaves the proxy box, in float64 (independent of both
+    restatements' f32 chains): NaN where the ray misses the box."""
+    M = {k: np.asarray(v, np.float64) for k, v in spec.matrices().items()}
+    n2d = M["world_inv"] @ M["cam_inv"] @ M["proj_inv"]
+    W, H = spec.width, spec.height
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    px, py = 2 * (ii + 0.5) / W - 1, 1 - 2 * (jj + 0.5) / H
+    def unproject(z):
+        v = np.einsum("rc,chw->rhw", n2d, np.stack([px, py, np.full_like(px, z), np.ones_like(px)]))
+        return v[:3] / v[3]
+    near, far = unproject(-1.0), unproject(1.0)
+    ray = (far - near) / np.linalg.norm(far - near, axis=0)
+    size = np.array(spec.pairs[0][0].shape[::-1], np.float64)[:, None, None]
+    with np.errstate(all="ignore"):
+        t1, t2 = (-0.5 - near) / ray, (size - 0.5 - near) / ray
+    t_exit, t_enter = np.maximum(t1, t2).min(axis=0), np.minimum(t1, t2).max(axis=0)
+    back = near + ray * t_exit
+    wx = M["world"][0, 0] * back[0] + M["world"][0, 1] * back[1] + M["world"][0, 2] * back[2] + M["world"][0, 3]
+    return np.where(t_enter <= t_exit, wx, np.nan)
+
+
+@pytest.mark.parametrize("mode", ["ANY", "ALL"])
+def test_clipping_planes_discard_rays_by_their_back_face_position(mode):
+    spec = make_golden.specs()["k1"]
+    base = lmip.render_spec(spec, nthreads=2)
+    n = spec.pairs[0][0].shape[0]
+    # plane 1: x >= n/2 is kept; plane 2: everything kept (ANY) / nothing clipped by it alone
+    spec.material = dict(spec.material, clipping_planes=[(1.0, 0.0, 0.0, n / 2.0), (0.0, 1.0, 0.0, -1e6)], clipping_mode=mode)
+    a = lmip.render_spec(spec, nthreads=2)
+    b = lmip_numpy.render_spec(spec)
+    np.testing.assert_array_equal(a.flags, b["flags"])
+    np.testing.assert_array_equal(a.label, b["label"])
+    np.testing.assert_array_equal(a.steps, b["steps"])
+    wx = _back_face_world_x(spec)
+    margin = 1e-3 * n
+    if mode == "ANY":
+        assert np.all(a.flags[wx < n / 2.0 - margin] == 0)                      # behind plane 1: discarded
+        keep = wx > n / 2.0 + margin
+        assert keep.sum() > 100 and (base.flags[keep] != 0).sum() > 100
+        np.testing.assert_array_equal(a.flags[keep], base.flags[keep])            # in front of both: untouched
+        np.testing.assert_array_equal(a.rgba[keep], base.rgba[keep])
+        assert (a.flags != base.flags).sum() > 100
+    else:
+        np.testing.assert_array_equal(a.flags, base.flags)                       # no point is behind BOTH planes
+
+
+def test_no_clipping_planes_is_the_default_and_changes_nothing():
+    spec = make_golden.specs()["demo"]
+    a = lmip.render_spec(spec, nthreads=2)
+    spec.material = dict(spec.material, clipping_planes=[], clipping_mode="ALL")
+    b = lmip.render_spec(spec, nthreads=2)
+    for plane in ("flags", "label", "steps", "rgba", "depth"):
+        np.testing.assert_array_equal(getattr(a, plane), getattr(b, plane))
+
+
+# ---- MIP render mode (FUTURE.md:97-120) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["k1", "k2"])
+def test_mip_mode_through_the_lmip_machine_equals_mip_stated_directly(name):
+    spec = make_golden.specs()[name]
+    spec.material = dict(spec.material, render_mode="mip")
+    a = lmip.render_spec(spec, nthreads=2)                 # LMIP state machine with MIP parameters (C)
+    b = lmip_numpy.render_spec(spec)                       # running maximum over the whole ray (numpy)
+    np.testing.assert_array_equal(a.flags, b["flags"])
+    np.testing.assert_array_equal(a.steps, b["steps"])
+    np.testing.assert_array_equal(a.label, b["label"])
+    np.testing.assert_allclose(a.rgba, b["rgba"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a.depth, b["depth"], rtol=0, atol=2e-6)
+    assert (a.flags == 1).sum() == 0 and (a.flags == 2).sum() > 500      # every fragment yields its maximum
+    full = dict(spec.material, render_mode="lmip", lmip_threshold=float("inf"))
+    spec.material = full
+    np.testing.assert_array_equal(a.steps, lmip.render_spec(spec, nthreads=2).steps)      # MIP walks the whole ray
