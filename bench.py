@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the LMIP sub-volume march on MI355X (BASELINE.json metric).
 
-A *step* of this bench is one frame: one pass of the hot path (``svr_render``:
-vs_main + fs_main + raycast of the reference's WGSL as one HIP kernel) over all
-rays of a 1920x1080 frame of BASELINE config 2 — 1024^3 uint8 density + uint32
-labels, 3 LODs, chunk shapes (16,16,48)/(8,8,48)/(4,4,48), ring shapes
-(32,32,11)/(64,64,11)/(64,64,6) chunks (2.36 GB of ring textures), camera K1
-(SURVEY.md §8d).  Ring buffers are resident in HBM before the timed region.
+A *step* of this bench is one frame: one pass of the hot path (``svr_render``: vs_main + fs_main + raycast of
+the reference's WGSL as one HIP kernel) over all rays of a 1920x1080 frame.  Ring buffers are resident in HBM
+before the timed region (config C4 streams new chunks into them DURING it: that is its point).
 
-``value`` = ray-steps of the frame / frame time in *full* march mode (threshold =
-+inf: every ray runs all its nsteps; the deterministic roofline number).  The
-realistic early-out LMIP mode (threshold 0.5) is reported in the ``lmip`` block.
+``--config`` (BASELINE.json ``configs``; the default is the one the metric is quoted on):
 
-N > 1 (launched by torch.distributed.run): ring buffers replicated per GPU, the
-frame dealt to ranks in interleaved row bands, one RCCL gather of the RGBA bands
-to rank 0 + an un-tile kernel per frame; strong scaling (one frame, N GPUs).
+* ``C2`` (default) 1024^3 uint8 density + uint32 labels, 3 LODs, chunk shapes (16,16,48)/(8,8,48)/(4,4,48), ring
+  shapes (32,32,11)/(64,64,11)/(64,64,6) chunks (2.36 GB of ring textures in the reference's layout), camera K1.
+* ``C5`` 2048^3, ~1 M labels (1,000,003), 256-entry HSV table, fog_density 0.05, lmip_threshold 0.3, rings
+  scaled x2 per axis; generated on the device.
+* ``C4`` 4096^3 generated chunk-wise behind a lazy backing array (never resident), K2 fly-through: every frame is
+  one render + ``center_on_position(asynchronous=True)``; reports the frame-time distribution and the host ->
+  ring upload rate.  (``--volume-n`` shrinks any config for rehearsals.)
+
+``value`` = ray-steps of the frame(s) / time in *full* march mode (threshold = +inf: every ray runs all its
+nsteps; the deterministic roofline number).  The realistic early-out LMIP mode is in the ``lmip`` block.
+The timed region of K steps is repeated (``spread``) and also run with one frame at a time (``sequential``).
+
+N > 1 (launched by torch.distributed.run): rings replicated per GPU, the frame dealt to ranks in interleaved
+row bands (``--tiling rows``) or as config 3's literal grid (``--tiling 2x4``), one gather of every rank's
+planes to rank 0 per frame over RCCL (``svr_gather_tiles``) + an un-tile kernel; strong scaling.
 """
 
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -31,21 +39,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0      # PCIe Gen5 x16 spec (same guide, chip-level parameters)
+PROFILE_ROUND = "r02"     # profiles/<round>/traffic.json: PMC-derived HBM bytes of the default workload
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 20; C4: 240)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--volume-n", dest="n", type=int, default=1024, help="volume edge (config 2: 1024)")
+    ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
+    ap.add_argument("--volume-n", dest="n", type=int, default=None, help="volume edge (C2 1024, C5 2048, C4 4096)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--camera", choices=["K1", "K2"], default="K1")
+    ap.add_argument("--camera", choices=["K1", "K2"], default=None, help="default: K1 (C4: the K2 fly-through)")
     ap.add_argument("--band-h", type=int, default=16)
+    ap.add_argument("--tiling", default="rows", help="N > 1: 'rows' (interleaved bands), 'grid', or '<gx>x<gy>' e.g. 2x4")
+    ap.add_argument("--planes", choices=["rgba", "all"], default="rgba", help="N > 1: gather RGBA only, or depth + label too")
+    ap.add_argument("--gather", choices=["svr", "torch"], default="svr",
+                    help="N > 1 transport: svr_gather_tiles (RCCL behind the C ABI) or torch.distributed.gather")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--in-flight", type=int, default=4,
-                    help="frames kept in flight on separate HIP streams (1: strictly one after the other)")
+                    help="frames kept in flight on separate HIP streams for `value` (the `sequential` block is always 1)")
+    ap.add_argument("--repeats", type=int, default=5, help="how often the timed region is repeated for `spread`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
@@ -53,30 +69,90 @@ def parse():
     ap.add_argument("--modes", default="full,lmip", help="march modes to time (full must be included)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo: rehearsal of the N>1 path when several ranks must "
-                         "share one GPU (bands are gathered through host memory; not a performance number)")
-    ap.add_argument("--check", action="store_true", help="also compare the sampled rows with the oracle")
+                         "share one GPU (regions are gathered through host memory; not a performance number)")
+    ap.add_argument("--check", action="store_true", help="also compare sampled rows with the oracle / the gathered frame with a single-GPU render")
     ap.add_argument("--force-collective", action="store_true",
-                    help="with --gpus 1: run the N > 1 pipeline (bands, RCCL gather, un-tile) in a one-rank process group")
+                    help="with --gpus 1: run the N > 1 pipeline (tiling, RCCL gather, un-tile) in a one-rank process group")
+    ap.add_argument("--blocking-too", action="store_true", help="C4: also time the fly-through with blocking reloads")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------
+# scene descriptions
+# ---------------------------------------------------------------------------------------------------
+def _ring_shapes(scale):
+    r = lambda v: max(2, round(v * scale))  # noqa: E731
+    return [(r(32), r(32), r(11)), (r(64), r(64), r(11)), (r(64), r(64), r(6))]
+
+
 def config2_spec(n, width, height, camera, pairs):
+    """BASELINE config 2 (and, shrunk by --volume-n, its rehearsal sizes): SURVEY.md 8d."""
     from sub_volume_renderer_amd import testing
 
-    s = n / 1024.0
-    ring_shapes = [(max(2, round(32 * s)), max(2, round(32 * s)), max(2, round(11 * s))),
-                   (max(2, round(64 * s)), max(2, round(64 * s)), max(2, round(11 * s))),
-                   (max(2, round(64 * s)), max(2, round(64 * s)), max(2, round(6 * s)))]
+    ring_shapes = _ring_shapes(n / 1024.0)
     spec = testing.synthetic_spec(
         n, width, height, inside=(camera == "K2"), threshold=0.5, fog_density=0.01, ncolors=4,
         chunk_shapes=[(16, 16, 48), (8, 8, 48), (4, 4, 48)], ring_shapes=ring_shapes,
         sizes=[None, (n // 2,) * 3, (n // 4,) * 3], pairs=pairs)
     # LOD0: default window (N-1)*C around the centre; LOD1/2: their whole level (SURVEY.md §8d)
-    r0 = ring_shapes[0]
-    c0 = spec.chunk_shapes[0]
-    size0 = tuple((a - 1) * b for a, b in zip(r0, c0))
+    size0 = tuple((a - 1) * b for a, b in zip(ring_shapes[0], spec.chunk_shapes[0]))
     spec.centers = [(spec.centers[0][0], [size0, (n // 2,) * 3, (n // 4,) * 3])]
     return spec
+
+
+def config5_spec(n, width, height, camera, pairs):
+    """BASELINE config 5: 2048^3, ~1 M labels, 256 hues, fog 0.05, threshold 0.3; rings x2 per axis, so every
+    level's window has the same share of its level as in C2 (LOD1/2 again hold their whole level)."""
+    from sub_volume_renderer_amd import testing
+
+    ring_shapes = _ring_shapes(n / 1024.0)
+    spec = testing.synthetic_spec(
+        n, width, height, inside=(camera == "K2"), threshold=0.3, fog_density=0.05, ncolors=256,
+        chunk_shapes=[(16, 16, 48), (8, 8, 48), (4, 4, 48)], ring_shapes=ring_shapes,
+        sizes=[None, (n // 2,) * 3, (n // 4,) * 3], pairs=pairs)
+    size0 = tuple((a - 1) * b for a, b in zip(ring_shapes[0], spec.chunk_shapes[0]))
+    spec.centers = [(spec.centers[0][0], [size0, (n // 2,) * 3, (n // 4,) * 3])]
+    return spec
+
+
+def config4_spec(n, width, height):
+    """BASELINE config 4: an n^3 volume that is never resident (lazy backing arrays generate blocks on demand),
+    C2's chunk and ring shapes, camera K2 inside the volume; every level gets its default window (N-1)*C."""
+    from sub_volume_renderer_amd import synth, testing
+
+    pairs = [(synth.LazyLod(n, k, labels=False), synth.LazyLod(n, k, labels=True)) for k in range(3)]
+    spec = testing.synthetic_spec(
+        n, width, height, inside=True, threshold=0.5, fog_density=0.01, ncolors=4,
+        chunk_shapes=[(16, 16, 48), (8, 8, 48), (4, 4, 48)], ring_shapes=_ring_shapes(1.0), sizes=None, pairs=pairs)
+    spec.centers = [(spec.cam_position, None)]                 # windows centred on the camera, as the demo scripts do
+    return spec
+
+
+def flythrough_poses(spec, frames, step=2.0):
+    """the K2 eye moves `step` voxels per frame along its view direction."""
+    import numpy as np
+
+    eye = np.array(spec.cam_position, float)
+    d = np.array(spec.cam_target, float) - eye
+    d /= np.linalg.norm(d)
+    return [(tuple(eye + d * step * k), tuple(eye + d * step * k + d)) for k in range(frames)]
+
+
+def kernel_source_hash():
+    """What `roofline.traffic` was measured on: the march kernel's sources (a PMC figure taken on another kernel
+    must not be carried along)."""
+    h = hashlib.sha256()
+    for name in ("march_kernel.hip", "svr_internal.h", "march_dispatch.hip"):
+        with open(os.path.join(ROOT, "sub_volume_renderer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def summarise(ms):
+    import numpy as np
+
+    a = np.sort(np.asarray(ms, float))
+    return {"n": int(a.size), "median_ms": float(np.median(a)), "min_ms": float(a[0]), "max_ms": float(a[-1])}
 
 
 def main():
@@ -95,6 +171,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if rank == 0:
         g.build_hip()
+        g.build_synth()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     ndev = torch.cuda.device_count()
     if args.backend == "gloo":
@@ -116,91 +193,124 @@ def main():
     from sub_volume_renderer_amd.distributed import TiledFrame
 
     dev = torch.device("cuda", local_rank)
-    n, W, H = args.n, args.width, args.height
+    cfg = args.config
+    n = args.n or {"C2": 1024, "C5": 2048, "C4": 4096}[cfg]
+    W, H = args.width, args.height
+    camera = args.camera or ("K2" if cfg == "C4" else "K1")
+    steps = args.steps if args.steps is not None else (240 if cfg == "C4" else 20)
+    n_labels = 1000003 if cfg == "C5" else 4096
+
+    # ---- the volume and its rings -------------------------------------------------------------------
     t0 = time.time()
-    pairs = [synth.volume(n, k, 4096, xp=torch, device=dev, slab=16 if n >= 512 else 64) for k in range(3)]
-    torch.cuda.synchronize()
+    if cfg == "C4":
+        spec = config4_spec(n, W, H)
+    else:
+        # LOD 0 from the closed form; the coarser levels with the GPU pyramid builder (svr_pool2x, the reference's
+        # 2x mean / max pooling rules) — bit-identical to synthesising every level (tests/test_pyramid.py)
+        from sub_volume_renderer_amd.pyramid import build_pyramid
+
+        d0, l0 = synth.volume(n, 0, n_labels, xp=torch, device=dev, slab=16 if n >= 512 else 64)
+        pairs = build_pyramid(d0, l0, 3)
+        torch.cuda.synchronize()
+        spec = (config5_spec if cfg == "C5" else config2_spec)(n, W, H, camera, pairs)
     t_gen = time.time() - t0
-    spec = config2_spec(n, W, H, args.camera, pairs)
     spec.ring_storage = args.ring_storage
+    synth.LazyLod.read_seconds, synth.LazyLod.read_bytes = 0.0, 0
     t0 = time.time()
     scene = testing.build(spec, device=local_rank)
     scene.volume.synchronize()
     t_load = time.time() - t0
     vol, cam = scene.volume, scene.camera
-    N.check(N.lib().svr_set_variant(vol._rings.handle, args.variant), "svr_set_variant")
+    handle = vol._rings.handle
+    N.check(N.lib().svr_set_variant(handle, args.variant), "svr_set_variant")
 
-    tiled = TiledFrame(W, H, rank, world, args.band_h, force_collective=args.force_collective)
+    def upload_stats(reset=False):
+        b, s = C.c_uint64(0), C.c_double(0.0)
+        N.check(N.lib().svr_upload_stats(handle, C.byref(b), C.byref(s), 1 if reset else 0), "svr_upload_stats")
+        return int(b.value), float(s.value)
+
+    fill_bytes, fill_seconds = upload_stats(reset=True)
+    fill_read_s = synth.LazyLod.read_seconds
+
+    tiled = TiledFrame(W, H, rank, world, args.band_h, force_collective=args.force_collective, tiling=args.tiling)
+    transport = "none"
+    if collective:
+        transport = "torch.distributed.gather"
+        if args.backend == "nccl" and args.gather == "svr" and tiled.init_comm(vol):
+            transport = tiled.transport
     region = tiled.region
     full_frame = FrameRegion.full(W, H)
     modes = [m for m in args.modes.split(",") if m]
     assert "full" in modes, "--modes must include full (the headline number)"
+    lmip_threshold = float(spec.material["lmip_threshold"])
 
     def set_mode(full):
-        vol.material.lmip_threshold = float("inf") if full else 0.5 * 255.0
+        vol.material.lmip_threshold = float("inf") if full else lmip_threshold
 
-    # ---- exact step / hit / pixel counts of the whole frame (instrumented kernel, untimed)
-    counts = {}
-    for mode in modes:
-        set_mode(mode == "full")
-        r = vol.render(cam, W, H, region=full_frame, count_steps=True)
+    def instrumented(camera_obj):
+        r = vol.render(camera_obj, W, H, region=full_frame, count_steps=True)
         torch.cuda.synchronize()
-        counts[mode] = dict(steps=int(r.steps.to(torch.int64).sum().item()),
-                            hits=int((r.flags == 2).sum().item()),
-                            frags=int((r.flags != 0).sum().item()))
-    vol._out_cache = {}
+        return dict(steps=int(r.steps.to(torch.int64).sum().item()), hits=int((r.flags == 2).sum().item()),
+                    frags=int((r.flags != 0).sum().item()))
 
-    # ---- outputs for the timed loop.  Successive frames are independent (camera poses are known ahead
-    # in a fly-through), so `in_flight` frames are kept in flight: frame k runs on stream k % in_flight
-    # with its own band buffer; on N > 1 each stream carries render -> RCCL gather -> un-tile of its
-    # frames, so frame k's collective and its tail of long rays overlap frame k+1's march.
-    F = max(1, args.in_flight)
-    vol._out_cache = {}
-    outs = []
-    for _ in range(F):
-        outs.append(vol._outputs(region.out_h, region.out_w, False))
-        vol._out_cache = {}
-    out = outs[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [torch.cuda.current_stream(dev)]
-    last_frame = [None]
-    frame_no = [0]
-    pipelined = collective
+    want_all = args.planes == "all"
 
-    def frame():
-        slot = frame_no[0] % F
-        frame_no[0] += 1
-        with torch.cuda.stream(streams[slot]):
-            if pipelined:
-                f = tiled.finish(slot, dst=0)               # frame k - F: wait for its gather, un-tile (rank 0)
-                if f is not None:
-                    last_frame[0] = f
-            res = vol.render(cam, W, H, region=region, out=outs[slot])
-            if pipelined and args.backend == "nccl":
-                tiled.gather_async(res.rgba, slot, dst=0, volume=vol)      # RCCL gather of this frame's RGBA bands
-            elif pipelined:
-                tiled.gather_async(res.rgba.cpu(), slot, dst=0)             # gloo rehearsal through host memory
+    # ---- frames in flight: frame k runs on stream k % F with its own output buffers; on N > 1 each stream
+    # carries render -> gather -> un-tile of its frames, so frame k's collective and its tail of long rays overlap
+    # frame k+1's march.
+    class FrameLoop:
+        def __init__(self, F):
+            self.F = F
+            self.outs = []
+            for _ in range(F):
+                vol._out_cache = {}
+                self.outs.append(vol._outputs(region.out_h, region.out_w, False))
+            vol._out_cache = {}
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [torch.cuda.current_stream(dev)]
+            self.k = 0
+            self.last = None
 
-    def drain():
-        if pipelined:
-            for k in range(frame_no[0] - F, frame_no[0]):                   # oldest first
-                if k >= 0:
-                    with torch.cuda.stream(streams[k % F]):
-                        f = tiled.finish(k % F, dst=0)
-                        if f is not None:
-                            last_frame[0] = f
+        def planes_of(self, res):
+            return (res.rgba, res.depth, res.label) if want_all else res.rgba
 
-    def timed(mode, steps, warmup):
+        def frame(self, camera_obj=None):
+            slot = self.k % self.F
+            self.k += 1
+            with torch.cuda.stream(self.streams[slot]):
+                if collective:
+                    f = tiled.finish(slot, dst=0)               # frame k - F: wait for its gather, un-tile (rank 0)
+                    if f is not None:
+                        self.last = f
+                res = vol.render(camera_obj or cam, W, H, region=region, out=self.outs[slot])
+                if collective and args.backend == "nccl":
+                    tiled.gather_async(self.planes_of(res), slot, dst=0, volume=vol)
+                elif collective:
+                    p = self.planes_of(res)
+                    tiled.gather_async(tuple(t.cpu() for t in p) if want_all else p.cpu(), slot, dst=0)   # gloo rehearsal
+            return res
+
+        def drain(self):
+            if collective:
+                for k in range(self.k - self.F, self.k):        # oldest first
+                    if k >= 0:
+                        with torch.cuda.stream(self.streams[k % self.F]):
+                            f = tiled.finish(k % self.F, dst=0)
+                            if f is not None:
+                                self.last = f
+
+    def timed(loop, mode, nframes, warmup):
+        """W untimed frames, then EXACTLY nframes bracketed by barrier + synchronize; max over ranks."""
         set_mode(mode == "full")
         for _ in range(warmup):
-            frame()
-        drain()
+            loop.frame()
+        loop.drain()
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        for _ in range(steps):
-            frame()
-        drain()                                          # the K-th frame's gather + un-tile are inside the timed region
+        for _ in range(nframes):
+            loop.frame()
+        loop.drain()                                     # the K-th frame's gather + un-tile are inside the timed region
         torch.cuda.synchronize()
         if collective:
             dist.barrier()
@@ -211,109 +321,229 @@ def main():
             dt = float(tt.item())
         return dt
 
-    dt_full = timed("full", args.steps, args.warmup)
-    dt_lmip = timed("lmip", args.steps, args.warmup) if "lmip" in modes else None
-
-    # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
-    def kernel_ms(mode, iters=10):
-        set_mode(mode == "full")
-        vol.prepare()
-        cb, fb = vol.camera_block(cam), vol.frame_block(W, H, region)
-        ob = N.Outputs()
-        ob.rgba, ob.depth, ob.label, ob.flags, ob.steps = (out.rgba.data_ptr(), out.depth.data_ptr(),
-                                                           out.label.data_ptr(), out.flags.data_ptr(), None)
-        ms = C.c_float(0)
-        N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)),
-                "svr_time_render")
-        return float(ms.value)
-
-    torch.cuda.synchronize()
-    k_full = kernel_ms("full")
-    k_lmip = kernel_ms("lmip") if "lmip" in modes else None
-
-    def algo_bytes(c, npix):
-        # 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
-        # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
-        return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
-
-    u8 = vol._rings.density_storage == "uint8"
-
-    def native_bytes(c, npix):
-        # what the kernel actually has to fetch with byte rings: 1 B per ray-step
-        return (1 if u8 else 4) * c["steps"] + 4 * c["hits"] + 25 * npix
-
     result = None
-    if world == 1:
-        npix = W * H
-        a_full = algo_bytes(counts["full"], npix) / (k_full * 1e-3) / 1e9
-        a_lmip = algo_bytes(counts["lmip"], npix) / (k_lmip * 1e-3) / 1e9 if k_lmip else None
-    if rank == 0:
-        ms_full = dt_full / args.steps * 1e3
-        ms_lmip = dt_lmip / args.steps * 1e3 if dt_lmip else None
-        result = {
-            "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
-            "value": counts["full"]["steps"] / (dt_full / args.steps) / 1e6,
-            "unit": "Mray-steps/s",
-            "frames_per_s": args.steps / dt_full,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_full,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"C2: {n}^3 u8 density + u32 labels, 3 LODs, chunks (16,16,48)/(8,8,48)/(4,4,48), "
-                            f"rings {spec.ring_shapes} chunks, {W}x{H}, camera {args.camera}, march_mode=full",
-                "ray_steps_per_frame": counts["full"]["steps"],
-                "rays_with_fragment": counts["full"]["frags"],
-                "parallelism": "single" if not collective else f"frame row-bands x{world} (band_h={args.band_h}) + RCCL gather",
-                "kernel_variant": args.variant,
-                "frames_in_flight": F,
-                "ring_storage": vol._rings.density_storage,
-            },
-        }
-        if dt_lmip:
-            result["lmip"] = {
-                "march_mode": "lmip threshold=0.5*255 fall_off=0.5 max_samples=10",
-                "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
-                "value": counts["lmip"]["steps"] / (dt_lmip / args.steps) / 1e6, "unit": "Mray-steps/s",
-                "frames_per_s": args.steps / dt_lmip, "ms_per_step": ms_lmip,
+    if cfg != "C4":
+        # ---- exact step / hit / pixel counts of the whole frame (instrumented kernel, untimed)
+        counts = {}
+        for mode in modes:
+            set_mode(mode == "full")
+            counts[mode] = instrumented(cam)
+        loop = FrameLoop(max(1, args.in_flight))
+        seq = loop if loop.F == 1 else FrameLoop(1)
+        dts = {}
+        for mode in modes:
+            first = timed(loop, mode, steps, args.warmup)                       # the contract's K steps
+            more = [timed(loop, mode, steps, 0) for _ in range(max(0, args.repeats - 1))]
+            one = [timed(seq, mode, steps, 1 if i == 0 else 0) for i in range(max(1, args.repeats))]
+            dts[mode] = (first, [first] + more, one)
+        out = loop.outs[0]
+
+        # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
+        def kernel_ms(mode, iters=10):
+            set_mode(mode == "full")
+            vol.prepare()
+            cb, fb = vol.camera_block(cam), vol.frame_block(W, H, region)
+            ob = N.Outputs()
+            ob.rgba, ob.depth, ob.label, ob.flags, ob.steps = (out.rgba.data_ptr(), out.depth.data_ptr(),
+                                                               out.label.data_ptr(), out.flags.data_ptr(), None)
+            ms = C.c_float(0)
+            N.check(N.lib().svr_time_render(handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)),
+                    "svr_time_render")
+            return float(ms.value)
+
+        torch.cuda.synchronize()
+        kms = {mode: sorted(kernel_ms(mode) for _ in range(3))[1] for mode in modes}     # median of 3 x 10 launches
+        es = {"uint8": 1, "uint16": 2}.get(vol._rings.density_storage, 4)
+
+        def algo_bytes(c, npix):
+            # 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
+            # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
+            return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
+
+        def native_bytes(c, npix):
+            return es * c["steps"] + 4 * c["hits"] + 25 * npix        # what the ring's element type really needs
+
+        if rank == 0:
+            first, rep, one = dts["full"]
+            workload = {"C2": f"C2: {n}^3 u8 density + u32 labels, 3 LODs",
+                        "C5": f"C5: {n}^3 u8 density + u32 labels ({n_labels} labels), 3 LODs, 256 hues, fog 0.05, threshold 0.3*255"}[cfg]
+            result = {
+                "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
+                "value": counts["full"]["steps"] / (first / steps) / 1e6,
+                "unit": "Mray-steps/s",
+                "frames_per_s": steps / first,
+                "n_gpus": world, "steps": steps, "warmup": args.warmup,
+                "ms_per_step": first / steps * 1e3,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {
+                    "workload": f"{workload}, chunks (16,16,48)/(8,8,48)/(4,4,48), rings {spec.ring_shapes} chunks, "
+                                f"{W}x{H}, camera {camera}, march_mode=full",
+                    "ray_steps_per_frame": counts["full"]["steps"],
+                    "rays_with_fragment": counts["full"]["frags"],
+                    "parallelism": "single" if not collective else
+                                   f"frame {'row-bands' if args.tiling == 'rows' else 'tiles ' + args.tiling} x{world}"
+                                   f"{' (band_h=%d)' % args.band_h if args.tiling == 'rows' else ''} + gather of "
+                                   f"{'rgba+depth+label' if want_all else 'rgba'} via {transport}",
+                    "kernel_variant": args.variant,
+                    "frames_in_flight": loop.F,
+                    "ring_storage": vol._rings.density_storage,
+                },
+                # the same K-step region repeated, and with ONE frame at a time (no overlap of tails and heads):
+                # per-frame kernel time <= sequential ms_per_step must hold inside this record
+                "spread": dict(summarise([d / steps * 1e3 for d in rep]), what=f"ms per step over repeats of the {steps}-step region, {loop.F} frames in flight"),
+                "sequential": dict(summarise([d / steps * 1e3 for d in one]), frames_in_flight=1,
+                                   value=counts["full"]["steps"] / (float(np.median(one)) / steps) / 1e6),
             }
-        result["setup_s"] = {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)}
-        if world == 1:
-            # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot be run from
-            # inside the process it profiles): profiles/r01/traffic.json, valid for the default workload only
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-            if os.path.exists(tpath) and (n, W, H, args.camera, args.variant, u8) == (1024, 1920, 1080, "K1", 0, True):
-                with open(tpath) as f:
-                    traffic = json.load(f)["traffic_bytes_per_launch"]
-            result["roofline"] = {
-                "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": a_full / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "march_span (full mode)", "kernel_ms": k_full,
-                "algorithmic_bytes": algo_bytes(counts["full"], W * H),
-                "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
-                "native_layout": {"bytes": native_bytes(counts["full"], W * H),
-                                  "achieved": native_bytes(counts["full"], W * H) / (k_full * 1e-3) / 1e9,
-                                  "note": "byte rings: 1 B/ray-step actually needed" if u8 else "same as reference layout"},
+            if "lmip" in dts:
+                lf, lrep, lone = dts["lmip"]
+                result["lmip"] = {
+                    "march_mode": f"lmip threshold={lmip_threshold:g} fall_off=0.5 max_samples=10",
+                    "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
+                    "value": counts["lmip"]["steps"] / (lf / steps) / 1e6, "unit": "Mray-steps/s",
+                    "frames_per_s": steps / lf, "ms_per_step": lf / steps * 1e3,
+                    "spread": summarise([d / steps * 1e3 for d in lrep]),
+                    "sequential": dict(summarise([d / steps * 1e3 for d in lone]), frames_in_flight=1),
+                }
+            result["setup_s"] = {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)}
+            if world == 1:
+                npix = W * H
+                a_full = algo_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9
+                # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot run from inside
+                # the process it profiles): written by tools/profile_bench.sh, valid only for the kernel and the
+                # workload it was taken on
+                traffic, traffic_source = None, None
+                tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
+                here = dict(config=cfg, n=n, width=W, height=H, camera=camera, variant=args.variant,
+                            ring_storage=vol._rings.density_storage, kernel_source_sha16=kernel_source_hash())
+                if os.path.exists(tpath):
+                    with open(tpath) as f:
+                        tj = json.load(f)
+                    if all(tj.get("workload", {}).get(k) == v for k, v in here.items()):
+                        traffic = tj["traffic_bytes_per_launch"]
+                        traffic_source = {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "command": tj.get("command"),
+                                          "kernel_source_sha16": tj["workload"]["kernel_source_sha16"]}
+                    else:
+                        traffic_source = {"file": f"profiles/{PROFILE_ROUND}/traffic.json",
+                                          "stale": "taken on another kernel build or workload: not carried over"}
+                result["roofline"] = {
+                    "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": a_full / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": "march_span (full mode)", "kernel_ms": kms["full"],
+                    "algorithmic_bytes": algo_bytes(counts["full"], npix),
+                    "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
+                    "native_layout": {"bytes": native_bytes(counts["full"], npix),
+                                      "achieved": native_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9,
+                                      "frac": native_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": f"{es} B/ray-step: what the {vol._rings.density_storage} rings really need"},
+                }
+                if traffic:
+                    result["roofline"]["traffic_frac"] = traffic / (kms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if "lmip" in kms:
+                    a_lmip = algo_bytes(counts["lmip"], npix) / (kms["lmip"] * 1e-3) / 1e9
+                    result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": kms["lmip"]}
+    else:
+        # ---- C4: the fly-through.  A step = one frame = render + center_on_position(asynchronous=True).
+        poses = flythrough_poses(spec, args.warmup + steps)
+        cams = []
+        for eye, target in poses:
+            spec.cam_position, spec.cam_target = eye, target
+            cams.append(spec.camera())
+        # full mode: every ray runs all its nsteps whatever the rings hold, so the exact step count of the path
+        # needs no streaming: one instrumented render per pose
+        set_mode(True)
+        path_steps = [instrumented(c)["steps"] for c in cams[args.warmup:]]
+        loop = FrameLoop(1)
+
+        def fly(mode, asynchronous):
+            """Back to the start, W untimed frames, then K timed ones; per-frame wall times (frame k = render, wait
+            for it as a display would, then move the ring windows)."""
+            set_mode(mode == "full")
+            vol.poll_uploads(wait=True)
+            vol.center_on_position(poses[0][0])                            # blocking: rings as at the start
+            vol.synchronize()
+            upload_stats(reset=True)
+            synth.LazyLod.read_seconds, synth.LazyLod.read_bytes = 0.0, 0
+            times = []
+            if collective:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_start = None
+            for k, (eye, _) in enumerate(poses):
+                if k == args.warmup:
+                    if collective:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t_start = time.perf_counter()
+                t = time.perf_counter()
+                loop.frame(cams[k])
+                loop.drain()
+                torch.cuda.current_stream(dev).synchronize()
+                vol.center_on_position(eye, asynchronous=asynchronous)
+                if k >= args.warmup:
+                    times.append((time.perf_counter() - t) * 1e3)
+            torch.cuda.synchronize()
+            if collective:
+                dist.barrier()
+            dt = time.perf_counter() - t_start
+            landed = vol.poll_uploads(wait=False)
+            vol.poll_uploads(wait=True)
+            ub, us = upload_stats()
+            if collective:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            a = np.sort(np.asarray(times))
+            return dict(dt=dt, frame_ms={"median": float(np.median(a)), "p99": float(a[min(len(a) - 1, int(0.99 * len(a)))]),
+                                         "max": float(a[-1]), "mean": float(a.mean()), "over_5ms": int((a > 5.0).sum())},
+                        upload={"staged_bytes": ub, "seconds_in_upload_calls": round(us, 4),
+                                "GBps": (ub / us / 1e9) if us > 0 else None,
+                                "frac_of_pcie_gen5_x16": (ub / us / 1e9 / PCIE_PEAK_GBS) if us > 0 else None,
+                                "source_read_seconds": round(synth.LazyLod.read_seconds, 3),
+                                "source_read_GBps": (synth.LazyLod.read_bytes / synth.LazyLod.read_seconds / 1e9) if synth.LazyLod.read_seconds else None,
+                                "all_loads_landed_at_last_frame": bool(landed)})
+
+        runs = {"full": fly("full", True)}
+        if "lmip" in modes:
+            runs["lmip"] = fly("lmip", True)
+        if args.blocking_too:
+            runs["full_blocking"] = fly("full", False)
+        if rank == 0:
+            r = runs["full"]
+            result = {
+                "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
+                "value": sum(path_steps) / r["dt"] / 1e6, "unit": "Mray-steps/s", "frames_per_s": steps / r["dt"],
+                "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": r["dt"] / steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {
+                    "workload": f"C4: {n}^3 volume generated chunk-wise behind a lazy array (never resident), 3 LODs, chunks "
+                                f"(16,16,48)/(8,8,48)/(4,4,48), rings {spec.ring_shapes} chunks, {W}x{H}, K2 fly-through "
+                                f"2 voxels/frame, center_on_position(asynchronous=True) every frame, march_mode=full",
+                    "ray_steps_total": int(sum(path_steps)),
+                    "parallelism": "single" if not collective else f"{args.tiling} x{world} via {transport}",
+                    "kernel_variant": args.variant, "frames_in_flight": 1, "ring_storage": vol._rings.density_storage,
+                },
+                "frame_ms": r["frame_ms"], "upload": r["upload"],
+                "initial_fill": {"staged_bytes": fill_bytes, "seconds_in_upload_calls": round(fill_seconds, 3),
+                                 "GBps": fill_bytes / fill_seconds / 1e9 if fill_seconds else None,
+                                 "frac_of_pcie_gen5_x16": fill_bytes / fill_seconds / 1e9 / PCIE_PEAK_GBS if fill_seconds else None,
+                                 "source_read_seconds": round(fill_read_s, 2), "wall_seconds": round(t_load, 2)},
+                "setup_s": {"describe": round(t_gen, 2), "initial_fill": round(t_load, 2)},
             }
-            if k_lmip:
-                result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": k_lmip}
+            for name in ("lmip", "full_blocking"):
+                if name in runs:
+                    q = runs[name]
+                    result[name] = {"frames_per_s": steps / q["dt"], "ms_per_step": q["dt"] / steps * 1e3,
+                                    "frame_ms": q["frame_ms"], "upload": q["upload"]}
+        counts = {"full": {"steps": int(np.mean(path_steps)), "hits": 0, "frags": 0}}
 
     # ---- CPU baseline: the oracle (a port: the reference itself cannot run offline) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import lmip as oracle_lmip
 
-        rings = []
-        for b in vol.wrapping_buffers:
-            d, l = b.read_ring(Roi((0, 0, 0), b.shape_in_pixels))
-            u = b.uniform_buffer.data
-            rings.append(dict(density=d, labels=l,
-                              offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
-                              shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
-                              scale=tuple(float(v) for v in u["scale_factor"])))
         # threads = the CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the
         # GPU box shows 256 hardware threads but grants 16 CPUs' worth of time to a one-GPU job)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -328,6 +558,18 @@ def main():
                     cores = allowed
         except (OSError, ValueError):
             pass
+        if cfg == "C4":                                      # the pose of the first timed frame, rings as they are now
+            spec.cam_position, spec.cam_target = poses[args.warmup]
+            vol.center_on_position(poses[args.warmup][0])
+            vol.synchronize()
+        rings = []
+        for b in vol.wrapping_buffers:
+            d, l = b.read_ring(Roi((0, 0, 0), b.shape_in_pixels))
+            u = b.uniform_buffer.data
+            rings.append(dict(density=d, labels=l,
+                              offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
+                              shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
+                              scale=tuple(float(v) for v in u["scale_factor"])))
         mats = spec.matrices()
         vdim = tuple(float(v) for v in vol._volume_dimensions)
         m_full = dict(spec.material)
@@ -338,16 +580,17 @@ def main():
         ref = oracle_lmip.render(rings, mats, vdim, m_full, W, H, region=cal, nthreads=cores)
         t_cal = time.perf_counter() - t
         rate = max(1.0, ref.steps.astype(np.int64).sum() / t_cal)
-        frac = min(1.0, args.cpu_seconds * rate / max(1, counts["full"]["steps"]))
+        frame_steps = counts["full"]["steps"]
+        frac = min(1.0, args.cpu_seconds * rate / max(1, frame_steps))
         stride = max(1, int(round(1.0 / frac)))
         nrows = -(-H // stride)
         sample = FrameRegion(0, 0, W, nrows, 1, stride)
-        est = frac * counts["full"]["steps"] / rate                     # seconds for one pass over the sample
+        est = frac * frame_steps / rate                                 # seconds for one pass over the sample
         reps = max(1, min(16, int(round(args.cpu_seconds / max(est, 1e-3))))) if stride == 1 else 1
         base = {}
         for mode in modes:
             m = dict(spec.material)
-            m["lmip_threshold"] = float("inf") if mode == "full" else 0.5 * 255.0
+            m["lmip_threshold"] = float("inf") if mode == "full" else lmip_threshold
             t = time.perf_counter()
             for _ in range(reps if mode == "full" else 1):
                 ref = oracle_lmip.render(rings, mats, vdim, m, W, H, region=sample, nthreads=cores)
@@ -365,32 +608,32 @@ def main():
             result["cpu_baseline"]["lmip_value"] = base["lmip"][0] / base["lmip"][1] / 1e6
         if args.check:
             set_mode(True)
-            res = vol.render(cam, W, H, region=sample, count_steps=True)
+            res = vol.render(spec.camera(), W, H, region=sample, count_steps=True)
             torch.cuda.synchronize()
             result["check"] = testing.compare(res, ref)
 
-    if rank == 0 and collective and args.check:
+    if collective and args.check and cfg != "C4":
         set_mode(True)
-        frame_full = vol.render(cam, W, H, region=full_frame)
+        frame_full = vol.render(cam, W, H, region=full_frame) if rank == 0 else None
         torch.cuda.synchronize()
-        set_mode(True)
-        frame()
-        drain()
+        loop.frame()
+        loop.drain()
         torch.cuda.synchronize()
-        got = last_frame[0]
-        got = got.to(frame_full.rgba.device)
-        bad = (got != frame_full.rgba).any(dim=-1)
-        result["check" if world > 1 else "check_gathered"] = {"gathered_frame_equals_single_gpu_render": bool(torch.equal(got, frame_full.rgba)),
-                           "mismatched_pixels": int(bad.sum().item()),
-                           "coloured_pixels_gathered": int((got[..., :3].abs().sum(-1) > 0).sum().item()),
-                           "coloured_pixels_single": int((frame_full.rgba[..., :3].abs().sum(-1) > 0).sum().item()),
-                           "alpha1_gathered": int((got[..., 3] == 1).sum().item()),
-                           "alpha1_single": int((frame_full.rgba[..., 3] == 1).sum().item()),
-                           "mismatched_rows": [int(v) for v in torch.nonzero(bad.any(dim=1)).flatten()[:12].tolist()]}
-    elif collective and args.check:
-        set_mode(True)
-        frame()
-        drain()
+        if rank == 0:
+            got = loop.last
+            names = ("rgba", "depth", "label") if want_all else ("rgba",)
+            got = got if want_all else (got,)
+            rep = {}
+            for name, gt in zip(names, got):
+                want = getattr(frame_full, name)
+                gt = gt.to(want.device)
+                bad = (gt != want)
+                bad = bad.any(dim=-1) if bad.dim() == 3 else bad
+                rep[name] = {"equal": bool(torch.equal(gt, want)), "mismatched_pixels": int(bad.sum().item())}
+            rep["gathered_frame_equals_single_gpu_render"] = all(v["equal"] for v in rep.values())
+            rep["alpha1_gathered"] = int((got[0][..., 3] == 1).sum().item())
+            rep["transport"] = transport
+            result["check" if world > 1 else "check_gathered"] = rep
     if rank == 0:
         print(json.dumps(result), flush=True)
     if collective:

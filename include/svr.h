@@ -198,6 +198,9 @@ int  svr_uploads_pending(svr_ctx* ctx, int* pending);
  * everything enqueued on the upload stream so far and returns its ticket (> 0); svr_ticket_pending
  * reports 1 while that event has not been reached.  Tickets older than the 64 most recent ones are
  * reported as done only after the oldest live one is (their event has been reused). */
+/* diagnostics: bytes that went through the pinned staging slots so far and the host wall-clock seconds spent
+ * inside svr_upload_region (packing rows, waiting for a free slot, enqueueing); reset = 1 zeroes both */
+int  svr_upload_stats(svr_ctx* ctx, uint64_t* staged_bytes, double* seconds_in_calls, int reset);
 int  svr_upload_ticket(svr_ctx* ctx, uint64_t* ticket);
 int  svr_ticket_pending(svr_ctx* ctx, uint64_t ticket, int* pending);
 
@@ -237,6 +240,30 @@ int  svr_set_variant(svr_ctx* ctx, int variant);
 int  svr_untile_stripes(svr_ctx* ctx, const void* gathered, void* frame_out,
                         int frame_w, int frame_h, int band_h, int nranks,
                         int out_h, int elem_bytes, void* stream);
+
+/* The same for config 3's literal geometry: a grid of grid_x x grid_y tiles of tile_w x tile_h pixels, tile
+ * (tx, ty) rendered by rank ty * grid_x + tx (svr_frame with x0 = tx * tile_w, y0 = ty * tile_h, band_h = out_h =
+ * tile_h, out_w = tile_w); gathered holds grid_x * grid_y blocks of tile_h * tile_w elements.  Tiles of the
+ * last column / row may hang over the frame edge (their excess pixels are padding). */
+int  svr_untile_grid(svr_ctx* ctx, const void* gathered, void* frame_out, int frame_w, int frame_h,
+                     int tile_w, int tile_h, int grid_x, int grid_y, int elem_bytes, void* stream);
+
+/* ---- the collective (the reference has none): every rank's rendered region -> root, over RCCL
+ * (xGMI on one node).  One process per GPU, one context per process.  Rank 0 makes an id
+ * (svr_comm_unique_id == ncclGetUniqueId, /opt/rocm/include/rccl/rccl.h:187), hands its SVR_COMM_ID_BYTES bytes to
+ * the other ranks by any channel (a file, MPI, torch.distributed), and every rank calls svr_comm_init
+ * (ncclCommInitRank, rccl.h:220; collective: returns once all ranks have joined).
+ * svr_gather_tiles enqueues on `stream`, for each of `nplanes` planes (RGBA, and depth / label / flags when they
+ * are wanted), the transfer of bytes_per_rank[p] bytes from every rank's local[p] into root's
+ * gathered[p] + rank * bytes_per_rank[p]: grouped ncclSend / ncclRecv (rccl.h:700,722 — what ncclGather, rccl.h:745,
+ * is made of), all planes and peers in one group.  DEVICE pointers; `gathered` is only read on root.  The call is
+ * ordered after the work already on `stream` (the render that wrote local) and asynchronous. */
+#define SVR_COMM_ID_BYTES 128
+int  svr_comm_unique_id(char out_id[SVR_COMM_ID_BYTES]);
+int  svr_comm_init(svr_ctx* ctx, const char id[SVR_COMM_ID_BYTES], int rank, int nranks);
+int  svr_comm_destroy(svr_ctx* ctx);
+int  svr_gather_tiles(svr_ctx* ctx, int nplanes, const void* const* local, void* const* gathered,
+                      const size_t* bytes_per_rank, int root, void* stream);
 
 /* ---- LOD pyramid builder (device pointers): one 2x2x2 pooling step with the rules of the reference's
  * offline builders — mode 0 = mean (scripts/create_mouse_multiscale.py:23-54; SVR_U8: floor(sum/8),

@@ -121,6 +121,7 @@ SIGNATURES = {
     "svr_publish_uploads": (C.c_int, [C.c_void_p]),
     "svr_mark_uploads": (C.c_int, [C.c_void_p]),
     "svr_uploads_pending": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "svr_upload_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int]),
     "svr_upload_ticket": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "svr_ticket_pending": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]),
     "svr_read_region": (C.c_int, [C.c_void_p, C.c_int, _I3, _I3, C.c_void_p, C.c_void_p]),
@@ -130,6 +131,13 @@ SIGNATURES = {
     "svr_set_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "svr_untile_stripes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "svr_untile_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "svr_comm_unique_id": (C.c_int, [C.c_char * 128]),
+    "svr_comm_init": (C.c_int, [C.c_void_p, C.c_char * 128, C.c_int, C.c_int]),
+    "svr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "svr_gather_tiles": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "svr_pool2x": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, _I3, C.c_int, C.c_int, C.c_void_p]),
     "svr_compose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                               C.POINTER(ComposeParams), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -6,6 +6,10 @@
 // Arithmetic contract (must stay bit-identical with oracle/lmip_oracle.c):
 // strict IEEE f32, NO fp contraction (-ffp-contract=off), expression order as
 // written in the WGSL; see DESIGN.md "operation-order contract".
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "svr_internal.h"
 
 namespace {
@@ -990,7 +994,9 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
         const int threads = 64 << (2 * p.block_waves_log2);
-        const size_t lds = p.density_esh == 0 ? (size_t)kBrickBytes * (threads / 64) : 0;
+        // (SVR_LDS_PER_WAVE: occupancy experiments — the LDS request per wave caps the waves per CU at 160 KiB / it)
+        static const size_t lds_per_wave = getenv("SVR_LDS_PER_WAVE") ? (size_t)atoi(getenv("SVR_LDS_PER_WAVE")) : (size_t)kBrickBytes;
+        const size_t lds = p.density_esh == 0 ? std::max((size_t)kBrickBytes, lds_per_wave) * (threads / 64) : 0;
         if (p.density_esh == 0) {
             if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
             else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(threads), lds, stream, p);

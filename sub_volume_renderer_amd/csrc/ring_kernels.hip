@@ -156,6 +156,20 @@ __global__ __launch_bounds__(256) void untile_kernel(const T* gathered, T* frame
     }
 }
 
+// gathered: [grid_y * grid_x][tile_h][tile_w]; frame pixel (x, y) lives in tile (x / tile_w, y / tile_h)
+template <typename T>
+__global__ __launch_bounds__(256) void untile_grid_kernel(const T* gathered, T* frame, int frame_w, int frame_h,
+                                                          int tile_w, int tile_h, int grid_x) {
+    const size_t n = (size_t)frame_w * (size_t)frame_h;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int x = (int)(i % (size_t)frame_w), y = (int)(i / (size_t)frame_w);
+        const int tx = x / tile_w, ty = y / tile_h;
+        const size_t rank = (size_t)ty * grid_x + tx;
+        frame[i] = gathered[(rank * tile_h + (size_t)(y - ty * tile_h)) * (size_t)tile_w + (size_t)(x - tx * tile_w)];
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t blocks = (n + 255) / 256;
     const size_t cap = 256 * 8;          // 256 CUs x 8 blocks, grid-stride the rest
@@ -223,6 +237,25 @@ hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w,
         hipLaunchKernelGGL((untile_kernel<uint8_t>), dim3(grid_for(n)), dim3(256), 0, stream,
                            static_cast<const uint8_t*>(gathered), static_cast<uint8_t*>(frame_out),
                            frame_w, frame_h, band_h, nranks, out_h);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t svr_launch_untile_grid(const void* gathered, void* frame_out, int frame_w, int frame_h,
+                                  int tile_w, int tile_h, int grid_x, int grid_y, int elem_bytes, hipStream_t stream) {
+    const size_t n = (size_t)frame_w * (size_t)frame_h;
+    if (n == 0) return hipSuccess;
+    (void)grid_y;
+    if (elem_bytes == 16)
+        hipLaunchKernelGGL((untile_grid_kernel<float4>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const float4*>(gathered), static_cast<float4*>(frame_out), frame_w, frame_h, tile_w, tile_h, grid_x);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL((untile_grid_kernel<uint32_t>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const uint32_t*>(gathered), static_cast<uint32_t*>(frame_out), frame_w, frame_h, tile_w, tile_h, grid_x);
+    else if (elem_bytes == 1)
+        hipLaunchKernelGGL((untile_grid_kernel<uint8_t>), dim3(grid_for(n)), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(gathered), static_cast<uint8_t*>(frame_out), frame_w, frame_h, tile_w, tile_h, grid_x);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

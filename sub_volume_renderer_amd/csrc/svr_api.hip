@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 #include "svr_internal.h"
@@ -27,15 +28,6 @@ void mat_vec4(const float* m, const float* v, float* r) {
 void mat_mul4(const float* a, const float* b, float* out) {
     for (int c = 0; c < 4; ++c) mat_vec4(a, b + 4 * c, out + 4 * c);
 }
-
-struct DeviceGuard {
-    int prev = -1; bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) { ok = hipSetDevice(dev) == hipSuccess; }
-        else prev = -1;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 int floor_div(int a, int b) { int q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; }
 
@@ -69,6 +61,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->have_published = false; c->colors_dev = nullptr; c->colors_cap = 0; c->material_set = false;
     c->variant = 0; c->slot_bytes = 0; c->next_slot = 0; c->ev_a = c->ev_b = nullptr;
     c->next_ticket = 1;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1;
     for (auto& t : c->tickets) t = nullptr;
     c->uploads_marker = nullptr; c->marker_set = false; c->dbg_dev = nullptr;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
@@ -76,7 +69,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
     c->density_storage = lods[0].density_storage;
     c->density_u8 = lods[0].density_storage == SVR_U8 ? 1 : 0;
-    c->staged_bytes = 0;
+    c->staged_bytes = 0; c->upload_seconds = 0.0;
 
     auto fail = [&](int code) { svr_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->render_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -123,6 +116,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
 int svr_destroy(svr_ctx* c) {
     if (!c) return SVR_OK;
     DeviceGuard guard(c->device);
+    if (c->comm) (void)svr_comm_destroy(c);
     if (c->render_stream) (void)hipStreamSynchronize(c->render_stream);
     if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
     if (c->density_all) (void)hipFree(c->density_all);
@@ -333,6 +327,10 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     // one uploader at a time: the staging slots and the enqueue order on the upload stream are shared
     // (the render thread may load synchronously while the streaming worker is inside this call)
     std::lock_guard<std::mutex> upload_lock(c->upload_mu);
+    struct Clock {                                          // time inside this call, for svr_upload_stats
+        svr_ctx* c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~Clock() { c->upload_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } clock{ c };
     rc = ensure_staging(c);
     if (rc) return rc;
     rc = uploads_after_render(c);
@@ -438,6 +436,15 @@ int svr_uploads_pending(svr_ctx* c, int* pending) {
     const hipError_t e = hipEventQuery(c->uploads_marker);
     if (e == hipErrorNotReady) { *pending = 1; return SVR_OK; }
     SVR_HIP_TRY(e);
+    return SVR_OK;
+}
+
+int svr_upload_stats(svr_ctx* c, uint64_t* staged_bytes, double* seconds_in_calls, int reset) {
+    SVR_REQUIRE(c, "svr_upload_stats: null ctx");
+    std::lock_guard<std::mutex> upload_lock(c->upload_mu);
+    if (staged_bytes) *staged_bytes = c->staged_bytes;
+    if (seconds_in_calls) *seconds_in_calls = c->upload_seconds;
+    if (reset) { c->staged_bytes = 0; c->upload_seconds = 0.0; }
     return SVR_OK;
 }
 
@@ -729,6 +736,17 @@ int svr_untile_stripes(svr_ctx* c, const void* gathered, void* frame_out, int fr
     DeviceGuard guard(c->device);
     hipStream_t s = static_cast<hipStream_t>(stream);       // NULL = default stream, as in svr_render
     SVR_HIP_TRY(svr_launch_untile(gathered, frame_out, frame_w, frame_h, band_h, nranks, out_h, elem_bytes, s));
+    return SVR_OK;
+}
+
+int svr_untile_grid(svr_ctx* c, const void* gathered, void* frame_out, int frame_w, int frame_h,
+                    int tile_w, int tile_h, int grid_x, int grid_y, int elem_bytes, void* stream) {
+    SVR_REQUIRE(c && gathered && frame_out, "svr_untile_grid: null argument");
+    SVR_REQUIRE(frame_w > 0 && frame_h > 0 && tile_w > 0 && tile_h > 0 && grid_x > 0 && grid_y > 0, "svr_untile_grid: bad geometry");
+    SVR_REQUIRE((int64_t)tile_w * grid_x >= frame_w && (int64_t)tile_h * grid_y >= frame_h, "svr_untile_grid: the tiles do not cover the frame");
+    DeviceGuard guard(c->device);
+    SVR_HIP_TRY(svr_launch_untile_grid(gathered, frame_out, frame_w, frame_h, tile_w, tile_h, grid_x, grid_y, elem_bytes,
+                                       static_cast<hipStream_t>(stream)));
     return SVR_OK;
 }
 

@@ -108,6 +108,7 @@ struct svr_ctx {
     int       density_storage;       // ring element type: SVR_F32 (reference layout), SVR_U8 or SVR_U16
     int       density_u8;            // density_storage == SVR_U8
     uint64_t  staged_bytes;          // bytes sent through the pinned staging slots so far (diagnostics)
+    double    upload_seconds;        // host wall-clock time spent inside svr_upload_region
     uint32_t* labels_all;
     size_t    density_all_bytes;
     size_t    lod_base_bytes[SVR_MAX_LODS];
@@ -147,6 +148,18 @@ struct svr_ctx {
     hipEvent_t tickets[kTickets];
     uint64_t   next_ticket;          // next ticket to hand out (first is 1)
     std::mutex ticket_mu;
+    // RCCL communicator of svr_comm_init (comm_rccl.hip); opaque here
+    void* comm;
+    int   comm_rank, comm_size;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 // error plumbing -------------------------------------------------------------
@@ -179,6 +192,8 @@ hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
 hipError_t svr_launch_gather(const void* ring_density, int ring_storage, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream);
+hipError_t svr_launch_untile_grid(const void* gathered, void* frame_out, int frame_w, int frame_h,
+                                  int tile_w, int tile_h, int grid_x, int grid_y, int elem_bytes, hipStream_t stream);
 hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w, int frame_h,
                              int band_h, int nranks, int out_h, int elem_bytes, hipStream_t stream);
 

@@ -152,3 +152,62 @@ def test_two_frames_in_flight_slots(tmp_path):
     yy, xx = np.meshgrid(np.arange(13), np.arange(16), indexing="ij")
     for k in range(5):
         np.testing.assert_array_equal(got[f"f{k}"][..., 0], 1000.0 * k + 16.0 * yy + xx)
+
+
+# ---- config 3's grid tiling ("2x4") and several planes per gather ---------------------------------------------------
+def test_grid_partition_is_exact():
+    for (W, H, world, tiling, want) in [(1920, 1080, 8, "2x4", (960, 270)), (1920, 1080, 8, "grid", (960, 270)),
+                                        (1920, 1080, 4, "2x2", (960, 540)), (65, 45, 6, "3x2", (22, 23)),
+                                        (10, 7, 2, "1x2", (10, 4))]:
+        seen = np.zeros((H, W), int)
+        for rank in range(world):
+            tf = TiledFrame(W, H, rank, world, tiling=tiling)
+            assert (tf.cols_per_rank, tf.rows_per_rank) == want
+            reg = tf.region
+            assert (reg.out_w, reg.out_h, reg.band_h) == (want[0], want[1], want[1])
+            rows, cols = tf.frame_rows_of(rank), tf.frame_cols_of(rank)
+            assert rows[0] == reg.y0 and cols[0] == reg.x0           # svr_frame mapping of a plain tile
+            ys = [y for y in rows if y >= 0]
+            xs = [x for x in cols if x >= 0]
+            seen[np.ix_(ys, xs)] += 1
+        assert np.all(seen == 1)
+    # BASELINE config 3: rank ty * 2 + tx renders the 960 x 270 tile (tx, ty)
+    tf = TiledFrame(1920, 1080, 5, 8, tiling="2x4")
+    assert (tf.region.x0, tf.region.y0) == (960, 540)
+    with pytest.raises(ValueError):
+        TiledFrame(64, 64, 0, 8, tiling="3x3")
+    with pytest.raises(ValueError):
+        TiledFrame(64, 64, 0, 8, tiling="diagonal")
+
+
+def _grid_worker(rank, world, port, tiling, W, H, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = testing.synthetic_spec(32, W, H, threshold=0.3)
+        tf = TiledFrame(W, H, rank, world, tiling=tiling)
+        ref = lmip.render_spec(spec, region=tf.region, nthreads=2)
+        planes = (torch.from_numpy(ref.rgba), torch.from_numpy(ref.depth), torch.from_numpy(ref.label.astype(np.int64)),
+                  torch.from_numpy(ref.flags))
+        frames = tf.gather(planes, dst=0)                 # RGBA + depth + label + flags in one call
+        if rank == 0:
+            np.savez(out_path, rgba=frames[0].numpy(), depth=frames[1].numpy(), label=frames[2].numpy(), flags=frames[3].numpy())
+        else:
+            assert frames is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tiling", [(2, "2x1"), (4, "2x2"), (3, "grid")])
+def test_gather_of_grid_tiles_and_all_planes_equals_full_frame(tmp_path, world, tiling):
+    W, H = 66, 45                      # neither extent divides evenly: edge tiles hang over the frame
+    out = str(tmp_path / "grid.npz")
+    mp.spawn(_grid_worker, args=(world, _free_port(), tiling, W, H, out), nprocs=world, join=True)
+    got = np.load(out)
+    full = lmip.render_spec(testing.synthetic_spec(32, W, H, threshold=0.3), nthreads=2)
+    np.testing.assert_array_equal(got["rgba"], full.rgba)
+    np.testing.assert_array_equal(got["depth"], full.depth)
+    np.testing.assert_array_equal(got["label"], full.label.astype(np.int64))
+    np.testing.assert_array_equal(got["flags"], full.flags)

@@ -122,7 +122,7 @@ def test_c_abi_rejects_bad_arguments_with_messages():
                                 L3(1, 64, 1024), None, 0, L3(0, 0, 0)), "svr_upload_region")
     f32 = np.zeros((16, 16, 32), np.float32)
     fails(lib.svr_upload_region(ctx, 0, I3(0, 0, 0), I3(32, 16, 16), C.c_void_p(f32.ctypes.data), 8,
-                                L3(4, 128, 2048), None, 0, L3(0, 0, 0)), "uint8")
+                                L3(4, 128, 2048), None, 0, L3(0, 0, 0)), "integer density storage")
     cam, fr, ob = N.Camera(), N.Frame(), N.Outputs()
     fr.frame_w, fr.frame_h, fr.out_w, fr.out_h, fr.band_h, fr.band_pitch = 8, 8, 8, 8, 8, 8
     fails(lib.svr_render(ctx, C.byref(cam), C.byref(fr), C.byref(ob), None), "null argument")

@@ -170,3 +170,198 @@ def test_one_rank_rccl_pipeline_equals_single_gpu_frame():
     assert res["config"]["parallelism"].startswith("frame row-bands x1")
     assert res["check_gathered"]["gathered_frame_equals_single_gpu_render"] is True
     assert res["check_gathered"]["alpha1_gathered"] > 1000
+
+
+# =====================================================================================================
+# BASELINE config 1, literally: the arrays, material, rings and camera of scripts/multi_scale.py:31-85
+# =====================================================================================================
+def test_config1_literal_multi_scale_script_480x480():
+    """(256,256,768)/(128,128,768)/(64,64,768) float arrays of tiled chunks, rings (2,2,2)/(4,4,4)/(8,8,8) chunks,
+    480 x 480 canvas, camera at (-19.81, 7.5, 7.5): every pixel against the oracle."""
+    import torch
+
+    scene = testing.build(testing.multiscale_demo_spec(480, 480, tiles=16))
+    assert [tuple(d.shape) for d, _ in scene.spec.pairs] == [(256, 256, 768), (128, 128, 768), (64, 64, 768)]
+    res = scene.volume.render(scene.camera, 480, 480, count_steps=True)
+    torch.cuda.synchronize()
+    ref = lmip.render_scene(scene)
+    rep = testing.compare(res, ref)
+    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
+    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    assert set(np.unique(ref.label[ref.flags == 2])) == {0, 1, 2} and rep["n_hit"] > 10000
+
+
+# =====================================================================================================
+# BASELINE config 5 at its stated size: 2048^3, ~1 M labels, 256 hues, fog 0.05, threshold 0.3
+# =====================================================================================================
+def _rings_from_device(vol):
+    rings = []
+    for b in vol.wrapping_buffers:
+        d, l = b.read_ring(Roi((0, 0, 0), b.shape_in_pixels))
+        u = b.uniform_buffer.data
+        rings.append(dict(density=d, labels=l, offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
+                          shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
+                          scale=tuple(float(v) for v in u["scale_factor"])))
+    return rings
+
+
+@pytest.fixture(scope="module")
+def c5():
+    import torch
+
+    import bench
+    from sub_volume_renderer_amd import synth
+    from sub_volume_renderer_amd.pyramid import build_pyramid
+
+    dev = torch.device("cuda", 0)
+    n, W, H = 2048, 1920, 1080
+    d0, l0 = synth.volume(n, 0, 1000003, xp=torch, device=dev, slab=16)
+    pairs = build_pyramid(d0, l0, 3)
+    torch.cuda.synchronize()
+    scene = testing.build(bench.config5_spec(n, W, H, "K1", pairs))
+    yield scene
+    del scene, pairs, d0, l0
+    torch.cuda.empty_cache()
+
+
+def test_c5_geometry_and_ring_addressing_property(c5):
+    from sub_volume_renderer_amd import synth
+
+    vol = c5.volume
+    assert [tuple(b.shape_in_pixels) for b in vol.wrapping_buffers] == [(1024, 1024, 1056), (1024, 1024, 1056), (512, 512, 576)]
+    assert vol._rings.density_storage == "uint8" and len(vol.material.colors) == 256
+    assert vol.material.fog_density == pytest.approx(0.05) and vol.material.lmip_threshold == pytest.approx(0.3 * 255)
+    rng = np.random.default_rng(5)
+    seen_labels = set()
+    for lod, buf in enumerate(vol.wrapping_buffers):
+        roi = buf._current_logical_roi_in_pixels.intersect(Roi((0, 0, 0), tuple(buf.backing_data.shape)))
+        ring = np.array(buf.shape_in_pixels)
+        for _ in range(5):
+            shape = np.minimum(np.array([4, 6, 40]), np.array(roi.shape))
+            off = np.array(roi.offset) + rng.integers(0, np.array(roi.shape) - shape + 1)
+            want_d, want_l = synth.block(2048, lod, off.tolist(), shape.tolist(), 1000003)
+            seen_labels.update(np.unique(want_l).tolist())
+            for a0 in range(shape[0]):
+                for a1 in range(0, shape[1], 2):
+                    q = (off + np.array([a0, a1, 0])) % ring
+                    run = int(min(shape[2], ring[2] - q[2]))
+                    d, l = buf.read_ring(Roi(tuple(int(v) for v in q), (1, 1, run)))
+                    np.testing.assert_array_equal(d[0, 0], want_d[a0, a1, :run].astype(np.float32))
+                    np.testing.assert_array_equal(l[0, 0], want_l[a0, a1, :run])
+    assert max(seen_labels) > 4096                         # the ~1 M label space is really in use
+
+
+def test_c5_config3_tiles_equal_full_frame(c5):
+    """The 2 x 4 grid of 960 x 270 tiles BASELINE configs 3 and 5 deal to 8 GPUs, rendered one after the other on
+    this GPU, against the single full-frame render: every plane, bit for bit."""
+    import torch
+
+    vol, cam, W, H = c5.volume, c5.camera, 1920, 1080
+    vol.material.lmip_threshold = 0.3 * 255.0
+    full = vol.render(cam, W, H, count_steps=True)
+    torch.cuda.synchronize()
+    ref = {k: getattr(full, k).clone() for k in ("rgba", "depth", "label", "flags", "steps")}
+    assert int((ref["flags"] == 2).sum()) > 100000
+    assert len(torch.unique(ref["label"][ref["flags"] == 2])) > 1000       # many distinct labels reach the screen
+    for ty in range(4):
+        for tx in range(2):
+            r = vol.render(cam, W, H, region=FrameRegion.tile(tx * 960, ty * 270, 960, 270), count_steps=True)
+            torch.cuda.synchronize()
+            for k in ref:
+                assert torch.equal(getattr(r, k), ref[k][ty * 270:(ty + 1) * 270, tx * 960:(tx + 1) * 960]), (k, tx, ty)
+
+
+@pytest.mark.parametrize("mode", ["lmip", "full"])
+def test_c5_oracle_parity_on_sampled_rows(c5, mode):
+    """Every 40th row of the 1920x1080 frame of the 2048^3 scene against the oracle fed with the rings read back
+    from HBM (1 M labels modulo a 256-entry HSV table, fog 0.05)."""
+    import torch
+
+    vol, cam, W, H = c5.volume, c5.camera, 1920, 1080
+    thr = 0.3 * 255.0 if mode == "lmip" else float("inf")
+    vol.material.lmip_threshold = thr
+    if "rings" not in c5.__dict__:
+        c5.__dict__["rings"] = _rings_from_device(vol)
+    sample = FrameRegion(0, 0, W, 27, 1, 40)
+    m = dict(c5.spec.material)
+    m["lmip_threshold"] = thr
+    ref = lmip.render(c5.rings, c5.spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), m, W, H, region=sample)
+    res = vol.render(cam, W, H, region=sample, count_steps=True)
+    torch.cuda.synchronize()
+    rep = testing.compare(res, ref)
+    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
+    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    assert rep["total_steps"] > 30_000_000
+    if mode == "full":
+        del c5.__dict__["rings"]
+
+
+# =====================================================================================================
+# BASELINE config 4 at its stated size: a 4096^3 volume that is never resident, streamed by a fly-through
+# =====================================================================================================
+def test_c4_4096_streamed_flythrough_rings_and_pixels_match_oracle():
+    """4096^3 behind lazy backing arrays (blocks generated on demand), C2's rings, K2 inside; 40 frames of the
+    fly-through with center_on_position(asynchronous=True) after every render.  Checked: the windows really
+    moved and reloaded; after the last load has landed the device rings equal the oracle's rings voxel for
+    voxel (ring addressing buf[pos % ring] == data[pos] included) and the published ROIs are the synchronous
+    ones; sampled rows of the last frame equal the oracle."""
+    import torch
+
+    import bench
+    from oracle import ring_oracle
+    from sub_volume_renderer_amd import synth
+
+    n, W, H = 4096, 1920, 1080
+    spec = bench.config4_spec(n, W, H)
+    assert [p[0].shape for p in spec.pairs] == [(4096,) * 3, (2048,) * 3, (1024,) * 3]
+    scene = testing.build(spec)
+    vol = scene.volume
+    start = [b._current_logical_roi_in_pixels for b in vol.wrapping_buffers]
+    poses = bench.flythrough_poses(spec, 40, step=6.0)         # 240 voxels of travel: every level crosses chunks
+    frames = 0
+    for eye, target in poses:
+        spec.cam_position, spec.cam_target = eye, target
+        vol.render(spec.camera(), W, H)
+        vol.center_on_position(eye, asynchronous=True)
+        frames += 1
+    vol.poll_uploads(wait=True)
+    torch.cuda.synchronize()
+    moved = [b._current_logical_roi_in_pixels != s for b, s in zip(vol.wrapping_buffers, start)]
+    assert all(moved), moved
+    # the oracle's host-side restatement, driven to the same final position (blocking loads)
+    orac = ring_oracle.OracleSubVolume(list(spec.pairs), list(spec.ring_shapes), list(spec.chunk_shapes),
+                                       world_inverse_matrix=np.linalg.inv(spec.world().matrix))
+    orac.center_on_position(poses[-1][0], None)
+    rings = []
+    for lod, (b, ob) in enumerate(zip(vol.wrapping_buffers, orac.wrapping_buffers)):
+        got = b._current_logical_roi_in_pixels
+        assert (tuple(got.offset), tuple(got.shape)) == ob.current_logical_roi_in_pixels
+        d, l = b.read_ring(Roi((0, 0, 0), b.shape_in_pixels))
+        # inside the published window every ring slot holds its voxel (slots outside it may hold older chunks)
+        roi = Roi(*ob.current_logical_roi_in_pixels).intersect(Roi((0, 0, 0), ob.backing_data.shape))
+        ring = np.array(b.shape_in_pixels)
+        idx = [np.arange(o, o + s) % r for o, s, r in zip(roi.offset, roi.shape, ring)]
+        np.testing.assert_array_equal(d[np.ix_(*idx)], ob.texture[np.ix_(*idx)])
+        np.testing.assert_array_equal(l[np.ix_(*idx)], ob.segmentations_texture[np.ix_(*idx)])
+        # and against the closed form itself, at a few places of the window
+        rng = np.random.default_rng(lod)
+        for _ in range(3):
+            shape = np.array([3, 5, 33])
+            off = np.array(roi.offset) + rng.integers(0, np.array(roi.shape) - shape + 1)
+            want_d, want_l = synth.block(n, lod, off.tolist(), shape.tolist())
+            q = [np.arange(o, o + s) % r for o, s, r in zip(off, shape, ring)]
+            np.testing.assert_array_equal(d[np.ix_(*q)], want_d.astype(np.float32))
+            np.testing.assert_array_equal(l[np.ix_(*q)], want_l)
+        u = b.uniform_buffer.data
+        rings.append(dict(density=d, labels=l, offset=tuple(int(v) for v in u["current_logical_offset_in_pixels"]),
+                          shape=tuple(int(v) for v in u["current_logical_shape_in_pixels"]),
+                          scale=tuple(float(v) for v in u["scale_factor"])))
+    sample = FrameRegion(0, 0, W, 27, 1, 40)
+    cam = spec.camera()
+    res = vol.render(cam, W, H, region=sample, count_steps=True)
+    torch.cuda.synchronize()
+    ref = lmip.render(rings, spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), spec.material, W, H, region=sample)
+    rep = testing.compare(res, ref)
+    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
+    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    assert rep["n_hit"] > 1000 and frames == 40

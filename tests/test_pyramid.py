@@ -47,7 +47,7 @@ def test_pool2x_bit_exact(shape):
 
 
 @pytest.mark.gpu
-def test_build_pyramid_equals_synthetic_lods_and_streams_at_hbm_rate():
+def test_build_pyramid_equals_synthetic_lods():
     import torch
 
     from sub_volume_renderer_amd.pyramid import build_pyramid
@@ -58,3 +58,30 @@ def test_build_pyramid_equals_synthetic_lods_and_streams_at_hbm_rate():
     for k in (1, 2):
         dk, lk = synth.volume(n, k, xp=torch, device=torch.device("cuda", 0))
         assert torch.equal(pairs[k][0], dk) and torch.equal(pairs[k][1], lk)
+
+
+@pytest.mark.gpu
+def test_pool_kernels_stream_at_a_sane_fraction_of_hbm_rate(capsys):
+    """One 2x pooling step of a 1024^3 level reads it once and writes an eighth: pure HBM streaming.  The rate is
+    printed (tools/exp_kernels.py records it under profiles/); the floor asserted here only catches a
+    pathological kernel (uncoalesced rows), not a slow box."""
+    import torch
+
+    from sub_volume_renderer_amd.pyramid import pool2x
+
+    n = 1024
+    for dtype, mode, es in ((torch.uint8, "mean", 1), (torch.int32, "max", 4)):
+        t = torch.randint(0, 200, (n, n, n), dtype=dtype, device="cuda")
+        pool2x(t, mode)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            pool2x(t, mode)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 5
+        gbs = n ** 3 * es * (1 + 1 / 8) / (ms * 1e-3) / 1e9
+        with capsys.disabled():
+            print(f"\npool2x {mode} {dtype}: {ms:.3f} ms, {gbs:.0f} GB/s ({gbs / 8000:.2f} of HBM peak)")
+        assert gbs > 800.0, (mode, gbs)
+        del t

@@ -1,19 +1,26 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py's roofline block (same command, full mode only so that every
-# march dispatch in the trace is the timed workload).  usage: tools/profile_bench.sh <tag>
-TAG=${1:-r01}
+# rocprofv3 evidence for bench.py's roofline block (same command, full mode only so that every march dispatch in
+# the trace is the timed workload): one --kernel-trace --stats pass, then separate --pmc passes (never combined with
+# other trace domains; FETCH_SIZE and WRITE_SIZE in passes of their own).  Writes gpurun_out/profile_<tag>/ and the
+# PMC-derived profiles/<round>/traffic.json (copy the summaries you want judged into profiles/ by hand).
+# usage: tools/profile_bench.sh <tag> [round]
+TAG=${1:-r02}; ROUND=${2:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --modes full --no-cpu-baseline --in-flight 1"   # one frame at a time: per-dispatch durations stay comparable with roofline.kernel_ms
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+ARGS="--steps 10 --warmup 2 --modes full --no-cpu-baseline --in-flight 1 --repeats 1"   # one frame at a time: per-dispatch durations stay comparable with roofline.kernel_ms
+CMD="python3 $ROOT/bench.py $ARGS"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUFFER_WAVEFRONTS_sum" \
             "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
             "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex march --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex march --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/pmc_$name.log; exit 1; }
 done
 grep -h '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
 python3 $ROOT/tools/pmc_summary.py $OUT march_span > $OUT/summary.txt 2>&1
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); head -1 $f > $OUT/kernel_stats_march.csv; grep march_ $f >> $OUT/kernel_stats_march.csv
+cp $f $OUT/kernel_stats_all.csv
+mkdir -p $ROOT/gpurun_out/profiles_$ROUND
+python3 $ROOT/tools/make_traffic.py $OUT $ROOT/gpurun_out/profiles_$ROUND/traffic.json "bench.py $ARGS" >> $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
