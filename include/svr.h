@@ -222,7 +222,8 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
 /* kernel variant selector for A/B measurement (results are identical for every value):
  * bits 0-3  kernel: 0 = default span march (one wave per workgroup), 1 = straightforward one-load-per-step
  *            march, 2 = span march with 2x2 waves per workgroup; +4 = brick slabs never start longer
- *            than their plain length (default: twice), +8 = start at four times
+ *            than their plain length (default: twice), +8 = no empty-space skipping in LMIP mode (default: waves skip
+ *            stretches whose macro-cell maxima stay below the threshold while no lane tracks a maximum)
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)

@@ -820,6 +820,64 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // power of two commutes with rounding): one multiply per axis instead of two
             const float ssx = L.ss[0], ssy = L.ss[1], ssz = L.ss[2];      // size * scale, multiplied on the host
 
+            // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
+            // cells of 8^3 ring slots, the largest value stored in the cell or in one of its 26 neighbours.  A
+            // lane looks up the cell under its sample of iteration i: while it travels less than one cell per axis
+            // over the next B batches (B = skip_batches: 8, 16 or 32 iterations by LOD), every one of those samples
+            // lies in that cell or a neighbour, so a maximum below the threshold proves them all insignificant.
+            // When that holds for every live lane over 4 such tests, and no lane is tracking a maximum, the wave
+            // advances 4 B batches without fetching a texel: results and executed-iteration counts are those of
+            // the reference, sample for sample (raycast.wgsl:35-44 does nothing on such samples).
+            int held = 0;                                    // batches of this run held back behind a vetoed test
+            do {
+            run += held; held = 0;
+            if (P.cells_all_bytes != 0u) {
+                const kparams_t Ps = fresh_params(P);
+                const int sb = Ps->lod[first].skip_batches;
+                if (sb > 0 && run >= 4 * sb) {
+                    const float reach = (float)(8 * sb);
+                    const bool slow = fmaxf(fmaxf(fabsf(R.step.x * ssx), fabsf(R.step.y * ssy)), fabsf(R.step.z * ssz)) * reach <= 6.5f;
+                    __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<void*>(Ps->cells_all), 0, (int)Ps->cells_all_bytes, 0x00020000);
+                    const uint32_t cbase = Ps->lod[first].cell_base, cdx = Ps->lod[first].cdim[0], cdy = Ps->lod[first].cdim[1];
+                    bool vetoed = false;
+                    while (run >= 4 * sb) {
+                        const bool live = alive && !finished && n < nsteps;
+                        texel_t v[4];
+                        const float stride = reach;
+                        float2_t iter = { (float)n, (float)n + stride };
+#pragma unroll
+                        for (int g = 0; g < 4; g += 2) {
+                            const Idx2 q = voxel_pair(R, iter, ssx, ssy, ssz);
+                            iter += 2.0f * stride;
+                            uint32_t wx0 = q.x0 + (uint32_t)L.addw[0], wy0 = q.y0 + (uint32_t)L.addw[1], wz0 = q.z0 + (uint32_t)L.addw[2];
+                            uint32_t wx1 = q.x1 + (uint32_t)L.addw[0], wy1 = q.y1 + (uint32_t)L.addw[1], wz1 = q.z1 + (uint32_t)L.addw[2];
+                            wx0 = min(wx0, wx0 - L.ring[0]); wy0 = min(wy0, wy0 - L.ring[1]); wz0 = min(wz0, wz0 - L.ring[2]);
+                            wx1 = min(wx1, wx1 - L.ring[0]); wy1 = min(wy1, wy1 - L.ring[1]); wz1 = min(wz1, wz1 - L.ring[2]);
+                            const uint32_t c0 = mad24(mad24(wz0 >> 3, cdy, wy0 >> 3), cdx, wx0 >> 3);
+                            const uint32_t c1 = mad24(mad24(wz1 >> 3, cdy, wy1 >> 3), cdx, wx1 >> 3);
+                            v[g] = fetch_density<ESH>(crsrc, (c0 << ESH) + cbase);
+                            v[g + 1] = fetch_density<ESH>(crsrc, (c1 << ESH) + cbase);
+                        }
+                        const texel_t m = texel_max(texel_max(texel_abs(v[0]), texel_abs(v[1])), texel_max(texel_abs(v[2]), texel_abs(v[3])));
+                        // a lane that tracks a maximum, moves too fast for the test, or sees a cell that may hold a
+                        // significant value vetoes the skip
+                        const bool veto = live && (found || !slow || m >= thr_raw);
+                        if (__builtin_amdgcn_ballot_w64(veto) != 0) { vetoed = true; break; }
+                        if (COUNT) { steps += live ? (uint32_t)(min(n + 32 * sb, nsteps) - n) : 0u; ++c_zero; }
+                        n += 32 * sb;
+                        run -= 4 * sb;
+                        if (__builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) == 0) { run = 0; break; }
+                    }
+                    if (vetoed) {
+                        // march one test's worth (a whole brick slab where bricks are staged), then test again
+                        int cap = 4 * sb;
+                        if (ESH == 0 && brick_mode && L.slab > 0) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
+                        if (run > cap) { held = run - cap; run = cap; }
+                    }
+                }
+            }
+
             // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a
             // slab (ic is monotone per axis: first and last sample bound the rest) is staged into LDS
             // with coalesced 16-byte loads; the slab is then gathered from LDS, not through the L1,
@@ -848,22 +906,29 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // 16-voxel groups aligned in RING space, so a group never straddles the wrap
                     const int gx0 = lx - ((lx + L.addw[0]) & 15);
                     const int ngx = ((hx - gx0) >> 4) + 1;
-                    const int lgx = ngx <= 1 ? 0 : (32 - __builtin_clz(ngx - 1));
                     const int ny = hy - ly + 1, nz = hz - lz + 1;
-                    const int groups = (ny * nz) << lgx;
-                    if (ny >= 512 || groups * 16 > kBrickBytes) {            // does not fit
+                    // LDS image: rows of gp 16-byte groups, planes of pz groups.  Both pitches are ODD numbers of
+                    // groups (one group = 4 banks): the 8 rows / planes a wave's 8 x 8 pixel tile touches at one
+                    // iteration then start in 8 different bank quads instead of 1, 2 or 4 (power-of-two pitches:
+                    // 70 % of the LDS cycles were bank conflicts), and only the ngx groups the box really spans
+                    // are fetched (a pitch rounded up to a power of two fetched up to twice that).
+                    const int gp = P.brick_pow2 ? (ngx <= 1 ? 1 : 1 << (32 - __builtin_clz(ngx - 1))) : (ngx | 1);
+                    const int pz = P.brick_pow2 ? ny * gp : ((ny * gp) | 1);
+                    if (ny >= 512 || pz * nz * 16 > kBrickBytes) {           // does not fit
                         if (brick_mode > 1) { --brick_mode; continue; }       // retry with half the slab
                         brick_mode = 0; break;                                // march direct from here on
                     }
-                    // One load instruction per (z plane, chunk of 64 >> lgx rows): a lane's source offset is
-                    // a per-lane constant (its row y and 16-voxel group) plus a wave-uniform z term, so the
-                    // loop body is one VALU add.  Lanes beyond the plane's rows are masked off (an LDS-DMA
-                    // lane writes at base + lane*16, so inactive lanes simply leave their slot alone).
-                    const int rows_per = 64 >> lgx;
-                    const int ly_lane = lane >> lgx;
-                    uint32_t wx = (uint32_t)(gx0 + ((lane & ((1 << lgx) - 1)) << 4) + L.addw[0]);
+                    // One load instruction per (z plane, chunk of 64 / gp rows): lane = row * gp + group fills its
+                    // 16-byte slot at base + lane * 16; a lane's source offset is a per-lane constant (its row y and
+                    // group) plus a wave-uniform z term, so the loop body is one VALU add.  Lanes of a padding
+                    // group, or beyond the plane's rows, are masked off (they leave their slot alone).
+                    const float rgp = __frcp_rn((float)gp);
+                    const int rows_per = (int)(64.5f * rgp);                 // floor(64 / gp): x.5 / gp is never an integer
+                    const int ly_lane = (int)(((float)lane + 0.5f) * rgp);   // lane / gp, exactly
+                    const int g_lane = lane - ly_lane * gp;
+                    uint32_t wx = (uint32_t)(gx0 + (g_lane << 4) + L.addw[0]);
                     wx = min(wx, wx - L.ring[0]);
-                    const uint32_t plane_bytes = (uint32_t)(ny << (lgx + 4));
+                    const uint32_t plane_bytes = (uint32_t)(pz << 4);
                     const uint32_t zpitch = L.ring[1] * L.rx4;                       // bytes per ring z plane
                     lap(9);
                     for (int yc = 0; yc < ny; yc += rows_per) {
@@ -871,8 +936,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         uint32_t wy = (uint32_t)(ly + yy + L.addw[1]);
                         wy = min(wy, wy - L.ring[1]);
                         const uint32_t lane_src = mad24(wy, L.rx4, L.base_bytes + wx);
-                        const uint32_t lds_chunk = (uint32_t)wave_lds + (uint32_t)(yc << (lgx + 4));
-                        if (yy < ny) {
+                        const uint32_t lds_chunk = (uint32_t)wave_lds + (uint32_t)((yc * gp) << 4);
+                        if (yy < ny && g_lane < ngx && ly_lane < rows_per) {
                             for (int zz = 0; zz < nz; ++zz) {
                                 uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);      // wave-uniform
                                 wz = min(wz, wz - L.ring[2]);
@@ -882,14 +947,13 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             }
                         }
                     }
-                    // LDS byte address of voxel (ix,iy,iz) = ((iz*ny + iy) << sh) + ix + bk
-                    const uint32_t sh = (uint32_t)lgx + 4u;
-                    const uint32_t bk = (uint32_t)wave_lds - (uint32_t)((((lz * ny + ly) << sh) + gx0));
+                    // LDS byte address of voxel (ix,iy,iz) = iy * (gp * 16) + iz * (pz * 16) + ix + bk
+                    const uint32_t bk = (uint32_t)wave_lds - (uint32_t)(((lz * pz + ly * gp) << 4) + gx0);
                     lap(3);
                     if (!(P.dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lap(4);
-                    // address = y * S + z * (ny * S) + (x + bk),  S = 1 << sh: one dot2 on the packed (y, z)
-                    const uint32_t kyz = (1u << sh) | ((uint32_t)(ny << sh) << 16);
+                    // one dot2 on the packed (y, z): y * rowpitch + z * planepitch + (x + bk)
+                    const uint32_t kyz = (uint32_t)(gp << 4) | ((uint32_t)(pz << 4) << 16);
                     for (int k = 0; k < slab / U; ++k) {
                         texel_t s[U];
                         float2_t iter = { (float)n, (float)n + 1.0f };
@@ -947,6 +1011,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 else lmip_batch(s, n, live, false);
                 n += U;
             }
+            } while (held > 0 && __builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) != 0);
             lap(6);
         }
     }

@@ -1,5 +1,6 @@
 // Host side of the C ABI declared in include/svr.h.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -67,6 +68,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
+    c->cells_raw_all = c->cells_dil_all = nullptr; c->cells_all_bytes = 0;
     c->density_storage = lods[0].density_storage;
     c->density_u8 = lods[0].density_storage == SVR_U8 ? 1 : 0;
     c->staged_bytes = 0; c->upload_seconds = 0.0;
@@ -107,6 +109,38 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
         c->lod[l].labels = c->labels_all + c->lod_base_bytes[l];
     }
+    {   // macro-cell maxima (empty-space skipping): one grid of 8^3-slot cells per LOD whose extents allow it
+        size_t cells = 0;
+        for (int l = 0; l < num_lods; ++l) {
+            LodStorage& L = c->lod[l];
+            L.cells_raw = L.cells_dil = nullptr; L.cell_base = 0;
+            for (int a = 0; a < 3; ++a) L.cdim[a] = L.ring[a] / 8;
+            if ((L.ring[0] | L.ring[1] | L.ring[2]) & 7) continue;
+            L.cell_base = cells;
+            cells += ((size_t)L.cdim[0] * L.cdim[1] * L.cdim[2] + 63) & ~(size_t)63;
+        }
+        c->cells_all_bytes = cells * des;
+        if (cells && c->cells_all_bytes < ((size_t)1 << 31)) {
+            if (hipMalloc(&c->cells_raw_all, c->cells_all_bytes) != hipSuccess ||
+                hipMalloc(&c->cells_dil_all, c->cells_all_bytes) != hipSuccess) {
+                svr_set_error("svr_create: out of device memory for the macro-cell grids");
+                return fail(SVR_ERR_NOMEM);
+            }
+            if (hipMemsetAsync(c->cells_raw_all, 0, c->cells_all_bytes, c->upload_stream) != hipSuccess ||
+                hipMemsetAsync(c->cells_dil_all, 0, c->cells_all_bytes, c->upload_stream) != hipSuccess) {
+                svr_set_error("svr_create: memset failed");
+                return fail(SVR_ERR_HIP);
+            }
+            for (int l = 0; l < num_lods; ++l) {
+                LodStorage& L = c->lod[l];
+                if ((L.ring[0] | L.ring[1] | L.ring[2]) & 7) continue;
+                L.cells_raw = static_cast<char*>(c->cells_raw_all) + L.cell_base * des;
+                L.cells_dil = static_cast<char*>(c->cells_dil_all) + L.cell_base * des;
+            }
+        } else {
+            c->cells_all_bytes = 0;
+        }
+    }
     if (hipEventRecord(c->uploads_published, c->upload_stream) != hipSuccess) return fail(SVR_ERR_HIP);
     c->have_published = true;
     *out_ctx = c;
@@ -121,6 +155,8 @@ int svr_destroy(svr_ctx* c) {
     if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
     if (c->density_all) (void)hipFree(c->density_all);
     if (c->labels_all) (void)hipFree(c->labels_all);
+    if (c->cells_raw_all) (void)hipFree(c->cells_raw_all);
+    if (c->cells_dil_all) (void)hipFree(c->cells_dil_all);
     for (auto& s : c->slot) {
         if (s.host) (void)hipHostFree(s.host);
         if (s.dev) (void)hipFree(s.dev);
@@ -273,6 +309,17 @@ static int ensure_staging(svr_ctx* c) {
     return SVR_OK;
 }
 
+// Scatter one block into a LOD's rings and bring the macro-cell maxima of the touched cells up to date
+// (same stream, right behind the scatter: a render that can see the new voxels sees their maxima too).
+static hipError_t scatter_into_ring(svr_ctx* c, int lod, const ScatterArgs& a, bool wrote_density) {
+    hipError_t e = svr_launch_scatter(a, c->upload_stream);
+    const LodStorage& L = c->lod[lod];
+    if (e == hipSuccess && wrote_density && L.cells_raw)
+        e = svr_launch_cell_update(L.density, c->density_storage, L.ring, L.cells_raw, L.cells_dil, L.cdim,
+                                   a.dst_off, a.shape, c->upload_stream);
+    return e;
+}
+
 // Copy rows [r0, r1) of a strided host block into a packed buffer (x fastest); a row index is z * shape[1] + y.
 static void pack_row_range(const char* src, size_t es, const int64_t st[3], const int32_t shape[3],
                            int64_t r0, int64_t r1, char* dst) {
@@ -374,7 +421,7 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
         a.dst_off[0] = dst_off[0]; a.dst_off[1] = dst_off[1] + y0; a.dst_off[2] = dst_off[2] + z0;
         a.shape[0] = shape[0]; a.shape[1] = by; a.shape[2] = bz;
         a.packed = 1;
-        SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
+        SVR_HIP_TRY(scatter_into_ring(c, lod, a, density != nullptr));
         SVR_HIP_TRY(hipEventRecord(S.done, c->upload_stream));
         S.used = true;
         c->staged_bytes += lofs + lbytes;
@@ -408,7 +455,7 @@ int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], cons
         a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i];
     }
     a.ring_density = L.density; a.ring_labels = L.labels;
-    SVR_HIP_TRY(svr_launch_scatter(a, c->upload_stream));
+    SVR_HIP_TRY(scatter_into_ring(c, lod, a, density != nullptr));
     return SVR_OK;
 }
 
@@ -483,6 +530,11 @@ int svr_clear_lod(svr_ctx* c, int lod) {
     std::lock_guard<std::mutex> upload_lock(c->upload_mu);
     SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * svr_dtype_size(c->density_storage), c->upload_stream));
     SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
+    if (L.cells_raw) {
+        const size_t cb = (size_t)L.cdim[0] * L.cdim[1] * L.cdim[2] * svr_dtype_size(c->density_storage);
+        SVR_HIP_TRY(hipMemsetAsync(L.cells_raw, 0, cb, c->upload_stream));
+        SVR_HIP_TRY(hipMemsetAsync(L.cells_dil, 0, cb, c->upload_stream));
+    }
     return SVR_OK;
 }
 
@@ -635,7 +687,9 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     const int brick_mask = P.brick_lod_mask;
     // Every wave starts with brick slabs of twice the plain length (the staged bytes per sample fall with the
     // slab length) and drops to the plain length at its first box that does not fit; variant bit 2: never long.
-    P.slab_long = (c->variant & 4) ? 0 : ((c->variant & 8) ? 2 : 1);              // bit 3: start at four times (experiment)
+    P.slab_long = (c->variant & 4) ? 0 : 1;
+    static const bool brick_pow2 = getenv("SVR_BRICK_POW2") != nullptr;       // A/B measurements only
+    P.brick_pow2 = brick_pow2 ? 1 : 0;
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
         float wx[4];
@@ -686,8 +740,21 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             bool ok = c->density_u8 && (Q.ring[0] & 15u) == 0u && (brick_mask >> l & 1);
             for (int a = 0; a < 3; ++a) ok = ok && (long long)Q.off[a] + (long long)Q.shape[a] < 32768;
             Q.slab = ok ? slab : 0;
+            // empty-space skipping: one test of the dilated cell under a sample vouches for the next
+            // `skip_batches` batches of 8 iterations (the lane's travel over them must stay under one cell: checked
+            // per lane in the kernel); coarser LODs advance less per iteration
+            Q.cell_base = (uint32_t)(L.cell_base * des);
+            Q.cdim[0] = (uint32_t)L.cdim[0]; Q.cdim[1] = (uint32_t)L.cdim[1];
+            Q.skip_batches = (L.cells_dil && P.lod_pow2[l]) ? slab / 16 : 0;
         }
     }
+    // skip only when some texel value can reach the threshold and not every one does: threshold = +inf (or NaN)
+    // is the "full" march, whose point is the traversal itself; variant bit 3 switches skipping off (A/B)
+    const bool skip = c->cells_dil_all && !(c->variant & 8) && P.lmip_threshold_raw > 0u &&
+                      (c->density_storage == SVR_F32 ? (m.lmip_threshold > 0.0f && m.lmip_threshold < INFINITY)
+                                                     : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u));
+    P.cells_all = skip ? c->cells_dil_all : nullptr;
+    P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;
     P.density_all = c->density_all;
     P.density_all_bytes = span_addressable(c) ? (uint32_t)c->density_all_bytes : 0u;
     P.density_esh = c->density_storage == SVR_U8 ? 0 : (c->density_storage == SVR_U16 ? 1 : 2);

@@ -31,6 +31,10 @@ struct LodParams {
     uint32_t rx4;              // row pitch of the density ring in bytes (ring[0] * element size)
     float    ss[3];            // size * scale (the fused per-axis factor of the fast paths when scale = 2^-k)
     int32_t  slab;             // brick slab length in iterations (0: this LOD never stages bricks)
+    // empty-space skipping: the dilated macro-cell maxima of this LOD inside MarchParams::cells_all
+    uint32_t cell_base;        // byte offset of the LOD's cell grid
+    uint32_t cdim[2];          // cells along x and y
+    int32_t  skip_batches;     // batches of 8 iterations one cell test vouches for (0: never skip on this LOD)
 };
 
 struct MarchParams {
@@ -65,6 +69,8 @@ struct MarchParams {
     uint32_t* dbg;                 // batch census of the instrumented build (8 counters) or NULL
     // all LOD density rings live in ONE allocation so a single buffer resource
     // (32-bit byte offsets, hardware range check) addresses every LOD
+    const void* cells_all;         // dilated macro-cell maxima of all LODs (null: no skipping)
+    uint32_t cells_all_bytes;
     const void* density_all;
     uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
     int32_t  density_esh;          // log2 of the density element size: 0 u8, 1 u16, 2 f32 (svr_lod_desc::density_storage)
@@ -74,6 +80,7 @@ struct MarchParams {
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
     int32_t slab_long;             // 1: brick slabs start at twice their plain length
+    int32_t brick_pow2;            // A/B: round the brick row pitch up to a power of two (the round-1 layout)
     int32_t block_waves_log2;      // span kernel: block = (1 << this)^2 wave tiles (0: one wave per block)
     const uint32_t* tile_order;    // blockIdx -> tile index (null: contiguous run of tiles per XCD)
     int32_t dbg_nowait;            // experiments only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
@@ -91,6 +98,11 @@ struct LodStorage {
     void*     density;
     uint32_t* labels;
     svr_lod_state state;
+    // macro-cell maxima (8^3 slots per cell) for empty-space skipping; null when an extent is not a multiple of 8
+    void*     cells_raw;
+    void*     cells_dil;
+    int32_t   cdim[3];
+    size_t    cell_base;       // element offset of this LOD's grid inside svr_ctx::cells_dil_all
 };
 
 struct StagingSlot {
@@ -110,6 +122,9 @@ struct svr_ctx {
     uint64_t  staged_bytes;          // bytes sent through the pinned staging slots so far (diagnostics)
     double    upload_seconds;        // host wall-clock time spent inside svr_upload_region
     uint32_t* labels_all;
+    void*     cells_raw_all;         // macro-cell maxima of all LODs (element type = the density ring's)
+    void*     cells_dil_all;
+    size_t    cells_all_bytes;
     size_t    density_all_bytes;
     size_t    lod_base_bytes[SVR_MAX_LODS];
     hipStream_t render_stream;
@@ -189,6 +204,8 @@ struct ScatterArgs {
     int32_t shape[3];
 };
 hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
+hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t ring_dims[3], void* raw, void* dil,
+                                  const int32_t cdim[3], const int32_t off[3], const int32_t shape[3], hipStream_t stream);
 hipError_t svr_launch_gather(const void* ring_density, int ring_storage, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream);

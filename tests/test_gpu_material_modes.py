@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
 def test_clipping_planes_match_oracle(mode, inside):
     spec = testing.synthetic_spec(64, 160, 96, inside=inside, threshold=0.4)
-    spec.material.update(clipping_planes=[(1.0, 0.2, 0.0, 30.0), (0.0, -1.0, 0.3, -50.0)], clipping_mode=mode)
+    # two planes through the volume's centre (31.5, 31.5, 31.5): each cuts the box faces — where rays exit — in half
+    spec.material.update(clipping_planes=[(1.0, 0.2, 0.0, 37.8), (0.0, -1.0, 0.3, -22.05)], clipping_mode=mode)
     scene = testing.build(spec)
     _, ref, rep = check(scene)
     plain = lmip.render_spec(testing.synthetic_spec(64, 160, 96, inside=inside, threshold=0.4))

@@ -296,3 +296,46 @@ def test_rings_beyond_the_span_kernels_24_bit_row_index_render_exactly():
     ref = lmip.render_spec(small)
     _assert_frame(res, ref, "huge ring")
     assert (ref.flags == 2).sum() > 50
+
+
+def test_zarr_v3_sharded_store_as_backing_data(tmp_path):
+    """The on-disk layout of the reference's pyramid builders (zarr v3 group, scale0..2, 16^3 chunks in 64^3
+    shards, zstd) read by the product's own reader: a fly-through over the stores gives the frames and rings of
+    the same fly-through over the numpy arrays the stores were written from."""
+    import os
+
+    import torch
+
+    from sub_volume_renderer_amd import synth, zarr3
+
+    n = 128
+    pairs = [synth.volume(n, k) for k in range(3)]
+    raw = zarr3.create_group(str(tmp_path / "raw.zarr"))
+    lab = zarr3.create_group(str(tmp_path / "labels.zarr"))
+    for k, (d, l) in enumerate(pairs):
+        c = (16, 16, 16) if k < 2 else (8, 8, 8)
+        zarr3.write_array(os.path.join(raw.path, f"scale{k}"), d, chunks=c, shards=(64, 64, 64) if k == 0 else None)
+        zarr3.write_array(os.path.join(lab.path, f"scale{k}"), l, chunks=c, shards=(64, 64, 64) if k == 0 else None)
+    raw, lab = zarr3.open_group(raw.path), zarr3.open_group(lab.path)
+    zpairs = [(raw[f"scale{k}"], lab[f"scale{k}"]) for k in range(3)]
+    kw = dict(inside=True, chunk_shapes=[(8, 8, 16), (4, 4, 16), (2, 2, 16)], ring_shapes=[(6, 6, 3), (12, 12, 3), (16, 16, 2)])
+    spec = testing.synthetic_spec(n, 160, 96, pairs=zpairs, **kw)
+    scene = testing.build(spec)
+    assert scene.volume._rings.density_storage == "uint8"          # dtype comes from the store's metadata
+    orac = lmip.oracle_volume(testing.synthetic_spec(n, 160, 96, pairs=pairs, **kw))
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    for k in range(5):
+        p = eye + d * 9.0 * k
+        spec.cam_position, spec.cam_target = tuple(p), tuple(p + d)
+        scene.volume.center_on_position(tuple(p), asynchronous=bool(k & 1))
+        scene.volume.poll_uploads(wait=True)
+        orac.center_on_position(tuple(p))
+        res = scene.volume.render(spec.camera(), spec.width, spec.height, count_steps=True)
+        torch.cuda.synchronize()
+        ref = lmip.render(lmip.rings_of(orac), spec.matrices(), orac.volume_dimensions_shader, spec.material, spec.width, spec.height)
+        _assert_frame(res, ref, ("zarr", k))
+    for b, ob in zip(scene.volume.wrapping_buffers, orac.wrapping_buffers):
+        np.testing.assert_array_equal(b.texture.data, ob.texture)
+        np.testing.assert_array_equal(b.segmentations_texture.data, ob.segmentations_texture)

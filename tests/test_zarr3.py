@@ -1,0 +1,142 @@
+"""The zarr v3 reader (sub_volume_renderer_amd/zarr3.py): the on-disk format of the stores the reference's pyramid
+builders write (scripts/create_mouse_multiscale.py:102-131).  No zarr library and no zarr-written fixture exist
+offline, so the reader is pinned against byte strings assembled by hand from the zarr v3 specification's layout,
+and against the module's own writer."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from sub_volume_renderer_amd import SubVolume, SubVolumeMaterial, zarr3
+
+
+def _write(path, rel, data):
+    full = os.path.join(path, *rel.split("/"))
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    with open(full, "wb") as f:
+        f.write(data)
+
+
+def test_crc32c_check_value():
+    assert zarr3.crc32c(b"123456789") == 0xE3069283          # the CRC-32C (Castagnoli) check value
+    assert zarr3.crc32c(b"") == 0
+
+
+def test_hand_assembled_plain_chunks_big_endian_and_missing_chunk(tmp_path):
+    root = str(tmp_path / "a.zarr")
+    meta = {"zarr_format": 3, "node_type": "array", "shape": [4, 5], "data_type": "uint16",
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": [2, 3]}},
+            "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
+            "fill_value": 7, "codecs": [{"name": "bytes", "configuration": {"endian": "big"}}], "attributes": {"k": 1}}
+    _write(root, "zarr.json", json.dumps(meta).encode())
+    want = np.full((4, 5), 7, np.uint16)
+    # chunk (0,0): rows 0-1, cols 0-2; chunk (1,1): rows 2-3, cols 3-5 (col 5 is padding); chunks (0,1), (1,0) missing
+    c00 = np.arange(6, dtype=np.uint16).reshape(2, 3) + 100
+    c11 = np.arange(6, dtype=np.uint16).reshape(2, 3) + 200
+    _write(root, "c/0/0", c00.astype(">u2").tobytes())     # stored big-endian, as the bytes codec says
+    _write(root, "c/1/1", c11.astype(">u2").tobytes())
+    want[0:2, 0:3] = c00
+    want[2:4, 3:5] = c11[:, :2]
+    a = zarr3.open_zarr(root)
+    assert (a.shape, a.dtype, a.chunks, a.shards, a.ndim) == ((4, 5), np.dtype("uint16"), (2, 3), None, 2)
+    assert a.attrs == {"k": 1}
+    np.testing.assert_array_equal(a[:, :], want)
+    np.testing.assert_array_equal(a[1:3, 2:5], want[1:3, 2:5])
+    np.testing.assert_array_equal(a[-1], want[-1])
+    np.testing.assert_array_equal(a[..., 4], want[:, 4])
+    np.testing.assert_array_equal(np.asarray(a), want)
+    assert a[3, 4] == want[3, 4]
+
+
+def test_hand_assembled_shard_with_index_at_end_and_v2_keys(tmp_path):
+    """One 4x4 shard of 2x2 inner chunks, two of them stored: body = chunk(0,0) | chunk(1,1); index = C-order
+    (offset, nbytes) pairs, 2^64-1 for the missing ones, little-endian u64, + crc32c."""
+    root = str(tmp_path / "s.zarr")
+    meta = {"zarr_format": 3, "node_type": "array", "shape": [4, 4], "data_type": "uint8",
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": [4, 4]}},
+            "chunk_key_encoding": {"name": "v2", "configuration": {"separator": "."}}, "fill_value": 0,
+            "codecs": [{"name": "sharding_indexed", "configuration": {
+                "chunk_shape": [2, 2], "codecs": [{"name": "bytes"}],
+                "index_codecs": [{"name": "bytes", "configuration": {"endian": "little"}}, {"name": "crc32c"}],
+                "index_location": "end"}}]}
+    _write(root, "zarr.json", json.dumps(meta).encode())
+    E = 2 ** 64 - 1
+    body = bytes([1, 2, 3, 4]) + bytes([9, 8, 7, 6])
+    index = struct.pack("<8Q", 0, 4, E, E, E, E, 4, 4)
+    _write(root, "0.0", body + index + struct.pack("<I", zarr3.crc32c(index)))
+    a = zarr3.ZarrV3Array(root)
+    assert a.chunks == (2, 2) and a.shards == (4, 4)
+    np.testing.assert_array_equal(a[:, :], np.array([[1, 2, 0, 0], [3, 4, 0, 0], [0, 0, 9, 8], [0, 0, 7, 6]], np.uint8))
+    # a corrupted index is refused
+    _write(root, "0.0", body + index + struct.pack("<I", 12345))
+    with pytest.raises(ValueError):
+        zarr3.ZarrV3Array(root)[:, :]
+
+
+@pytest.mark.parametrize("compressor", [None, "gzip", "zstd"])
+@pytest.mark.parametrize("shards,index_location", [(None, "end"), ((32, 32, 32), "end"), ((32, 16, 32), "start")])
+def test_round_trip_of_the_reference_builders_layout(tmp_path, compressor, shards, index_location):
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 255, (40, 33, 70), dtype=np.uint8)
+    data[8:24, :, :] = 0                                   # whole chunks of fill value: not stored
+    root = str(tmp_path / "r.zarr")
+    a = zarr3.write_array(root, data, chunks=(8, 8, 16), shards=shards, compressor=compressor, index_location=index_location)
+    assert a.chunks == (8, 8, 16) and a.shape == data.shape and a.dtype == np.uint8
+    np.testing.assert_array_equal(a[:, :, :], data)
+    for _ in range(20):
+        lo = [int(rng.integers(0, n)) for n in data.shape]
+        hi = [int(rng.integers(l, n + 1)) for l, n in zip(lo, data.shape)]
+        sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+        np.testing.assert_array_equal(a[sl], data[sl])
+    stored = sum(len(files) for _, _, files in os.walk(root)) - 1
+    full = int(np.prod([-(-n // c) for n, c in zip(data.shape, shards or (8, 8, 16))]))
+    assert 0 < stored < full or shards is not None         # all-fill chunks have no file (plain layout)
+
+
+def test_labels_uint32_float32_and_group_of_scales(tmp_path):
+    rng = np.random.default_rng(4)
+    g = zarr3.create_group(str(tmp_path / "labels.zarr"), {"multiscales": "scale0..2"})
+    arrays = {}
+    for k in range(3):
+        n = 32 >> k
+        arrays[k] = rng.integers(0, 2 ** 32, (n, n, n), dtype=np.uint32)
+        zarr3.write_array(os.path.join(g.path, f"scale{k}"), arrays[k], chunks=(16 >> k,) * 3 if k < 2 else (8, 8, 8),
+                          shards=(16, 16, 16) if k == 0 else None)
+    grp = zarr3.open_group(str(tmp_path / "labels.zarr"))
+    assert grp.keys() == ["scale0", "scale1", "scale2"] and "scale1" in grp and "scale9" not in grp
+    for k in range(3):
+        np.testing.assert_array_equal(grp[f"scale{k}"][:, :, :], arrays[k])
+    f = rng.random((10, 12), dtype=np.float32)
+    fa = zarr3.write_array(str(tmp_path / "f.zarr"), f, chunks=(4, 5), compressor="zstd", fill_value=float("nan"))
+    np.testing.assert_array_equal(fa[:, :], f)
+
+
+def test_unsupported_codecs_fail_loudly(tmp_path):
+    root = str(tmp_path / "b.zarr")
+    meta = {"zarr_format": 3, "node_type": "array", "shape": [4], "data_type": "uint8",
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": [4]}},
+            "chunk_key_encoding": {"name": "default"}, "fill_value": 0,
+            "codecs": [{"name": "bytes"}, {"name": "blosc", "configuration": {"cname": "zstd"}}]}
+    _write(root, "zarr.json", json.dumps(meta).encode())
+    _write(root, "c/0", b"\x00" * 20)
+    with pytest.raises(NotImplementedError, match="blosc"):
+        zarr3.ZarrV3Array(root)[:]
+    with pytest.raises(FileNotFoundError):
+        zarr3.ZarrV3Array(str(tmp_path))                   # not a store at all
+    _write(str(tmp_path / "g"), "zarr.json", json.dumps({"zarr_format": 3, "node_type": "group"}).encode())
+    with pytest.raises(ValueError):
+        zarr3.ZarrV3Array(str(tmp_path / "g"))             # a group is not an array
+
+
+def test_subvolume_takes_chunk_shapes_from_zarr_arrays(tmp_path):
+    """``chunk_shape_in_pixels=None``: the chunking comes from the base array's ``.chunks`` (_wobject.py:46-53),
+    which for a sharded array is the inner chunk shape."""
+    data = np.zeros((32, 32, 32), np.uint8)
+    seg = np.zeros((32, 32, 32), np.uint32)
+    d = zarr3.write_array(str(tmp_path / "raw.zarr"), data + 1, chunks=(8, 8, 16), shards=(16, 16, 32))
+    s = zarr3.write_array(str(tmp_path / "seg.zarr"), seg + 1, chunks=(8, 8, 16), shards=(16, 16, 32))
+    vol = SubVolume(SubVolumeMaterial(0.5), [(d, s)], (3, 3, 2))
+    assert tuple(vol.wrapping_buffers[0].chunk_shape_in_pixels) == (8, 8, 16)
+    assert tuple(vol.wrapping_buffers[0].shape_in_pixels) == (24, 24, 32)
