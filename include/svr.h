@@ -294,7 +294,7 @@ int  svr_lod_device_ptrs(svr_ctx* ctx, int lod, void** density, void** labels);
 
 /* diagnostics: batch census accumulated by instrumented renders (outputs.steps != NULL):
  * [0] general batches, [1] direct fast batches, [2] brick batches, [3] brick slabs, [4] runs,
- * [5] all-zero batches, [6] waves; batches are per wave, 8 iterations each */
+ * [5] all-zero batches, [6] waves, [7] batches skipped as empty space; batches are per wave, 8 iterations each */
 int  svr_debug_counters(svr_ctx* ctx, uint32_t out[8], int reset);
 /* diagnostics: shader-clock cycles of wave residency per kernel section, summed over the waves of the
  * instrumented renders: [0] prologue (ray set-up, event search), [1] span refresh + run length, [2] general

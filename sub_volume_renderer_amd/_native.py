@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvr_hip.so")
+LIB_PATH = os.environ.get("SVR_LIB") or os.path.join(_HERE, "csrc", "libsvr_hip.so")      # SVR_LIB: A/B builds (tools/ab_build.py)
 
 SVR_MAX_LODS = 8
 SVR_PIX_DISCARD, SVR_PIX_MISS, SVR_PIX_HIT = 0, 1, 2

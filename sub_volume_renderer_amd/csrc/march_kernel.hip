@@ -380,6 +380,14 @@ __device__ __forceinline__ uint32_t texel_abs(uint32_t t) { return t; }
 __device__ __forceinline__ float texel_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ uint32_t texel_max(uint32_t a, uint32_t b) { return max(a, b); }
 
+// texel read from the LDS brick image
+template <int ESH>
+__device__ __forceinline__ typename Texel<ESH>::type lds_texel(const uint8_t* lds, uint32_t a) {
+    if constexpr (ESH == 2) return *reinterpret_cast<const float*>(lds + a);
+    else if constexpr (ESH == 1) return (uint32_t)*reinterpret_cast<const uint16_t*>(lds + a);
+    else return (uint32_t)lds[a];
+}
+
 // texel fetch through the range-checked buffer resource
 template <int ESH>
 __device__ __forceinline__ typename Texel<ESH>::type fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
@@ -522,8 +530,7 @@ struct LodEvents {
     int cx, cy, cz;      // wrap-constant change iterations per axis
 };
 
-// LDS brick geometry (u8 storage): one private region per wave
-constexpr int kBrickBytes = 8192;      // per wave; 4 waves per block -> 32 KiB per block
+// LDS bricks: one private region of MarchParams::brick_bytes per wave (dynamic LDS, see launch_nl)
 
 template <int NL, int U, bool COUNT, int ESH>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
@@ -572,12 +579,19 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     };
 
     // (the ray lives in registers: it is assembled from selects, never written through a pointer under a branch)
+#ifdef SVR_EXP_OLD_RAY
+    Ray R;
+    R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
+    const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
+    const int nsteps = frag ? R.nsteps : 0;
+#else
     Ray Rs;
     Rs.nsteps = 0; Rs.start = { 0.f, 0.f, 0.f }; Rs.step = { 0.f, 0.f, 0.f };
     const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, Rs);
     const int nsteps = frag ? Rs.nsteps : 0;
     const Ray R = { { frag ? Rs.start.x : 0.f, frag ? Rs.start.y : 0.f, frag ? Rs.start.z : 0.f },
                     { frag ? Rs.step.x : 0.f, frag ? Rs.step.y : 0.f, frag ? Rs.step.z : 0.f }, nsteps };
+#endif
 
     // ---- exact per-LOD event iterations
     // ic is monotone along the ray, so its values at the first and last sample bound every other
@@ -694,9 +708,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // of each quad).  Probe it: at one iteration, count how many lanes hit a line that no lower lane of
     // their quad hits; > kBrickQuadLines lookups per load -> stage bricks.  P.brick: 0 never, 1 probe, 2 always.
     int brick_mode = 0;                              // wave-uniform: 0 gathers only, k > 0 brick slabs of 2^(k-1) times the plain length
-    if (ESH == 0 && P.brick) {
+    if (P.brick) {
         const float pf = (float)min(max(nsteps - 1, 0), 256);
-        const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> 7;       // 128 voxels per line
+        const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> (7 - ESH);   // 128 bytes per line
         const int qy = (int)((R.start.y + pf * R.step.y) * P.size[1]);
         const int qz = (int)((R.start.z + pf * R.step.z) * P.size[2]);
         const int key = frag ? ((qz * 4099 + qy) * 64 + (qx & 63)) : -1 - lane;
@@ -710,10 +724,10 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const bool use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;   // lookups per full wave-load
         brick_mode = use_brick ? 1 + P.slab_long : 0;
     }
-    const int wave_lds = wave * kBrickBytes;
+    const int wave_lds = wave * P.brick_bytes;
 
     // diagnostics of the instrumented build (COUNT): wave-level batch census
-    int c_general = 0, c_direct = 0, c_brick = 0, c_slabs = 0, c_runs = 0, c_zero = 0;
+    int c_general = 0, c_direct = 0, c_brick = 0, c_slabs = 0, c_runs = 0, c_zero = 0, c_skip = 0;
     int n = 0;                                       // wave-uniform: every ray starts at iteration 0
     lap(0);
     while (true) {
@@ -821,68 +835,91 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             const float ssx = L.ss[0], ssy = L.ss[1], ssz = L.ss[2];      // size * scale, multiplied on the host
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
-            // cells of 8^3 ring slots, the largest value stored in the cell or in one of its 26 neighbours.  A
-            // lane looks up the cell under its sample of iteration i: while it travels less than one cell per axis
-            // over the next B batches (B = skip_batches: 8, 16 or 32 iterations by LOD), every one of those samples
-            // lies in that cell or a neighbour, so a maximum below the threshold proves them all insignificant.
-            // When that holds for every live lane over 4 such tests, and no lane is tracking a maximum, the wave
+            // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
+            // starts at each cell.  A lane looks at its samples of iterations i and i + 8 B (B = skip_batches): it
+            // travels at most one cell per axis between them (checked per lane), and its voxel index is monotone
+            // along the ray, so every sample in between lies in the block that starts at the smaller of the two
+            // cell coordinates: a block maximum below the threshold proves them all insignificant.  When that
+            // holds for every live lane over 4 such stretches, and no lane is tracking a maximum, the wave
             // advances 4 B batches without fetching a texel: results and executed-iteration counts are those of
             // the reference, sample for sample (raycast.wgsl:35-44 does nothing on such samples).
             int held = 0;                                    // batches of this run held back behind a vetoed test
             do {
             run += held; held = 0;
+#ifndef SVR_EXP_NO_SKIP
             if (P.cells_all_bytes != 0u) {
                 const kparams_t Ps = fresh_params(P);
                 const int sb = Ps->lod[first].skip_batches;
                 if (sb > 0 && run >= 4 * sb) {
                     const float reach = (float)(8 * sb);
-                    const bool slow = fmaxf(fmaxf(fabsf(R.step.x * ssx), fabsf(R.step.y * ssy)), fabsf(R.step.z * ssz)) * reach <= 6.5f;
+                    const uint32_t cs = (uint32_t)Ps->lod[first].cshift;
+                    const bool slow = fmaxf(fmaxf(fabsf(R.step.x * ssx), fabsf(R.step.y * ssy)), fabsf(R.step.z * ssz)) * reach <=
+                                      (float)(1u << cs) - 0.5f;
                     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<void*>(Ps->cells_all), 0, (int)Ps->cells_all_bytes, 0x00020000);
-                    const uint32_t cbase = Ps->lod[first].cell_base, cdx = Ps->lod[first].cdim[0], cdy = Ps->lod[first].cdim[1];
-                    bool vetoed = false;
+                    const uint32_t cbase = Ps->lod[first].cell_base;
+                    const uint32_t cdx = Ps->lod[first].cdim[0], cdy = Ps->lod[first].cdim[1], cdz = Ps->lod[first].cdim[2];
+                    bool vetoed = false, tracking_only = false;
                     while (run >= 4 * sb) {
                         const bool live = alive && !finished && n < nsteps;
-                        texel_t v[4];
-                        const float stride = reach;
-                        float2_t iter = { (float)n, (float)n + stride };
+                        // unwrapped cell coordinates ((index + addw) >> cs, in [0, 2 * cells)) of the samples at the 5
+                        // stretch borders: iterations n, n + 8B, n + 16B, n + 24B and the LAST one of the group,
+                        // n + 32B - 1 (the next iteration may already lie beyond this run: another LOD, another wrap);
+                        // none beyond the lane's last sample
+                        const float lastf = fminf((float)(nsteps - 1), (float)n + 4.0f * reach - 1.0f);
+                        uint32_t px[5], py[5], pz[5];
 #pragma unroll
-                        for (int g = 0; g < 4; g += 2) {
+                        for (int g = 0; g < 6; g += 2) {
+                            const float i0 = (float)n + reach * (float)g;
+                            const float2_t iter = { fminf(i0, lastf), fminf(i0 + reach, lastf) };
                             const Idx2 q = voxel_pair(R, iter, ssx, ssy, ssz);
-                            iter += 2.0f * stride;
-                            uint32_t wx0 = q.x0 + (uint32_t)L.addw[0], wy0 = q.y0 + (uint32_t)L.addw[1], wz0 = q.z0 + (uint32_t)L.addw[2];
-                            uint32_t wx1 = q.x1 + (uint32_t)L.addw[0], wy1 = q.y1 + (uint32_t)L.addw[1], wz1 = q.z1 + (uint32_t)L.addw[2];
-                            wx0 = min(wx0, wx0 - L.ring[0]); wy0 = min(wy0, wy0 - L.ring[1]); wz0 = min(wz0, wz0 - L.ring[2]);
-                            wx1 = min(wx1, wx1 - L.ring[0]); wy1 = min(wy1, wy1 - L.ring[1]); wz1 = min(wz1, wz1 - L.ring[2]);
-                            const uint32_t c0 = mad24(mad24(wz0 >> 3, cdy, wy0 >> 3), cdx, wx0 >> 3);
-                            const uint32_t c1 = mad24(mad24(wz1 >> 3, cdy, wy1 >> 3), cdx, wx1 >> 3);
-                            v[g] = fetch_density<ESH>(crsrc, (c0 << ESH) + cbase);
-                            v[g + 1] = fetch_density<ESH>(crsrc, (c1 << ESH) + cbase);
+                            px[g] = (q.x0 + (uint32_t)L.addw[0]) >> cs; py[g] = (q.y0 + (uint32_t)L.addw[1]) >> cs; pz[g] = (q.z0 + (uint32_t)L.addw[2]) >> cs;
+                            if (g + 1 < 5) {
+                                px[g + 1] = (q.x1 + (uint32_t)L.addw[0]) >> cs; py[g + 1] = (q.y1 + (uint32_t)L.addw[1]) >> cs;
+                                pz[g + 1] = (q.z1 + (uint32_t)L.addw[2]) >> cs;
+                            }
+                        }
+                        texel_t v[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            // the block that starts at the smaller cell coordinate per axis, wrapped onto the ring of cells
+                            uint32_t bx = min(px[g], px[g + 1]), by = min(py[g], py[g + 1]), bz = min(pz[g], pz[g + 1]);
+                            bx = min(bx, bx - cdx); by = min(by, by - cdy); bz = min(bz, bz - cdz);
+                            v[g] = fetch_density<ESH>(crsrc, (mad24(mad24(bz, cdy, by), cdx, bx) << ESH) + cbase);
                         }
                         const texel_t m = texel_max(texel_max(texel_abs(v[0]), texel_abs(v[1])), texel_max(texel_abs(v[2]), texel_abs(v[3])));
-                        // a lane that tracks a maximum, moves too fast for the test, or sees a cell that may hold a
+                        // a lane that tracks a maximum, moves too fast for the test, or passes a block that may hold a
                         // significant value vetoes the skip
-                        const bool veto = live && (found || !slow || m >= thr_raw);
-                        if (__builtin_amdgcn_ballot_w64(veto) != 0) { vetoed = true; break; }
-                        if (COUNT) { steps += live ? (uint32_t)(min(n + 32 * sb, nsteps) - n) : 0u; ++c_zero; }
+                        const bool occupied = live && !found && (!slow || m >= thr_raw);
+                        const unsigned long long occ_mask = __builtin_amdgcn_ballot_w64(occupied);
+                        if (occ_mask != 0 || __builtin_amdgcn_ballot_w64(live && found) != 0) {
+                            vetoed = true;
+                            tracking_only = occ_mask == 0;         // every vetoing lane is already following a maximum
+                            break;
+                        }
+                        if (COUNT) { steps += live ? (uint32_t)(min(n + 32 * sb, nsteps) - n) : 0u; c_skip += 4 * sb; }
                         n += 32 * sb;
                         run -= 4 * sb;
                         if (__builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) == 0) { run = 0; break; }
                     }
                     if (vetoed) {
                         // march one test's worth (a whole brick slab where bricks are staged), then test again
+                        // (a lane that is following a maximum is done within lmip_max_samples more samples: march just
+                        // long enough for that, with plain gathers, and come back to skipping)
                         int cap = 4 * sb;
-                        if (ESH == 0 && brick_mode && L.slab > 0) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
+                        if (brick_mode && L.slab > 0) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
+                        if (tracking_only && (P.skip_flags & 1)) cap = min(cap, 2);
                         if (run > cap) { held = run - cap; run = cap; }
                     }
                 }
             }
+#endif
 
             // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a
             // slab (ic is monotone per axis: first and last sample bound the rest) is staged into LDS
             // with coalesced 16-byte loads; the slab is then gathered from LDS, not through the L1,
             // which serves gathers one lane-quad at a time.
-            if (ESH == 0) {
+            {
                 // slab length (host: about 12 ring voxels of travel; 0 where this LOD cannot stage bricks)
                 // (a wave starts with slabs of twice that length: the staged bytes per sample fall with the slab
                 // length; at its first box that does not fit the LDS region it drops to the plain length)
@@ -904,8 +941,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     lap(8);
                     if (lx == big) { run = 0; break; }                   // no live lane left
                     // 16-voxel groups aligned in RING space, so a group never straddles the wrap
-                    const int gx0 = lx - ((lx + L.addw[0]) & 15);
-                    const int ngx = ((hx - gx0) >> 4) + 1;
+                    constexpr int GSH = 4 - ESH;                             // log2 of the voxels in a 16-byte group
+                    const int gx0 = lx - ((lx + L.addw[0]) & ((1 << GSH) - 1));
+                    const int ngx = ((hx - gx0) >> GSH) + 1;
                     const int ny = hy - ly + 1, nz = hz - lz + 1;
                     // LDS image: rows of gp 16-byte groups, planes of pz groups.  Both pitches are ODD numbers of
                     // groups (one group = 4 banks): the 8 rows / planes a wave's 8 x 8 pixel tile touches at one
@@ -914,7 +952,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // are fetched (a pitch rounded up to a power of two fetched up to twice that).
                     const int gp = P.brick_pow2 ? (ngx <= 1 ? 1 : 1 << (32 - __builtin_clz(ngx - 1))) : (ngx | 1);
                     const int pz = P.brick_pow2 ? ny * gp : ((ny * gp) | 1);
-                    if (ny >= 512 || pz * nz * 16 > kBrickBytes) {           // does not fit
+                    if (ny >= 512 || pz * nz * 16 > P.brick_bytes) {         // does not fit
                         if (brick_mode > 1) { --brick_mode; continue; }       // retry with half the slab
                         brick_mode = 0; break;                                // march direct from here on
                     }
@@ -926,8 +964,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const int rows_per = (int)(64.5f * rgp);                 // floor(64 / gp): x.5 / gp is never an integer
                     const int ly_lane = (int)(((float)lane + 0.5f) * rgp);   // lane / gp, exactly
                     const int g_lane = lane - ly_lane * gp;
-                    uint32_t wx = (uint32_t)(gx0 + (g_lane << 4) + L.addw[0]);
+                    uint32_t wx = (uint32_t)(gx0 + (g_lane << GSH) + L.addw[0]);
                     wx = min(wx, wx - L.ring[0]);
+                    wx <<= ESH;                                              // byte offset inside the ring row
                     const uint32_t plane_bytes = (uint32_t)(pz << 4);
                     const uint32_t zpitch = L.ring[1] * L.rx4;                       // bytes per ring z plane
                     lap(9);
@@ -947,8 +986,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             }
                         }
                     }
-                    // LDS byte address of voxel (ix,iy,iz) = iy * (gp * 16) + iz * (pz * 16) + ix + bk
-                    const uint32_t bk = (uint32_t)wave_lds - (uint32_t)(((lz * pz + ly * gp) << 4) + gx0);
+                    // LDS byte address of voxel (ix,iy,iz) = iy * (gp * 16) + iz * (pz * 16) + ix * element size + bk
+                    const uint32_t bk = (uint32_t)wave_lds - (uint32_t)(((lz * pz + ly * gp) << 4) + (gx0 << ESH));
                     lap(3);
                     if (!(P.dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lap(4);
@@ -961,15 +1000,15 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         for (int u = 0; u < U; u += 2) {
                             const Idx2p v = voxel_pair_packed(R, iter, ssx, ssy, ssz);
                             iter += 2.0f;
-                            const uint32_t a0 = dot2_u16(v.yz0, kyz, v.x0 + bk);
-                            const uint32_t a1 = dot2_u16(v.yz1, kyz, v.x1 + bk);
-                            s[u] = lds_all[a0];
-                            s[u + 1] = lds_all[a1];
+                            const uint32_t a0 = dot2_u16(v.yz0, kyz, shl_add_c<ESH>(v.x0, bk));
+                            const uint32_t a1 = dot2_u16(v.yz1, kyz, shl_add_c<ESH>(v.x1, bk));
+                            s[u] = lds_texel<ESH>(lds_all, a0);
+                            s[u + 1] = lds_texel<ESH>(lds_all, a1);
                         }
                         // pin the zero-extended bytes where they are loaded (ds_read_u8 already extends;
                         // otherwise the extension is re-done with a v_and per sample in the consumer block)
 #pragma unroll
-                        for (int u = 0; u < U; ++u) asm("" : "+v"(s[u]));
+                        for (int u = 0; u < U; ++u) if constexpr (ESH != 2) asm("" : "+v"(s[u]));
                         {
                             const bool lv = alive && !finished && n < nsteps;
                             // keep the no-tail case a compile-time constant (its per-sample tests fold away)
@@ -1020,7 +1059,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         atomicAdd(P.dbg + 0, (uint32_t)c_general); atomicAdd(P.dbg + 1, (uint32_t)c_direct);
         atomicAdd(P.dbg + 2, (uint32_t)c_brick);   atomicAdd(P.dbg + 3, (uint32_t)c_slabs);
         atomicAdd(P.dbg + 4, (uint32_t)c_runs);    atomicAdd(P.dbg + 5, (uint32_t)c_zero);
-        atomicAdd(P.dbg + 6, 1u);
+        atomicAdd(P.dbg + 6, 1u);                  atomicAdd(P.dbg + 7, (uint32_t)c_skip);
     }
     Hit h;
     h.found = found; h.sample = samp; h.steps = steps;
@@ -1059,9 +1098,7 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
         const int threads = 64 << (2 * p.block_waves_log2);
-        // (SVR_LDS_PER_WAVE: occupancy experiments — the LDS request per wave caps the waves per CU at 160 KiB / it)
-        static const size_t lds_per_wave = getenv("SVR_LDS_PER_WAVE") ? (size_t)atoi(getenv("SVR_LDS_PER_WAVE")) : (size_t)kBrickBytes;
-        const size_t lds = p.density_esh == 0 ? std::max((size_t)kBrickBytes, lds_per_wave) * (threads / 64) : 0;
+        const size_t lds = (size_t)p.brick_bytes * (threads / 64);
         if (p.density_esh == 0) {
             if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
             else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(threads), lds, stream, p);

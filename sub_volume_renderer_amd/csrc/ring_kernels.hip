@@ -117,15 +117,16 @@ __global__ __launch_bounds__(256) void scatter_rows16(const ScatterArgs a, uint3
 
 // ---------------------------------------------------------------------------------------------------
 // Macro-cell maxima for empty-space skipping (march_kernel.hip, LMIP mode).  Per LOD, the ring is cut into
-// cells of 8 x 8 x 8 slots; `raw` holds the largest |value| stored in a cell, `dil` the largest raw value of
-// the cell and its 26 neighbours on the ring torus.  Both are maintained here, on the upload stream, right
-// behind every scatter: the march reads only `dil`.  Conservative by construction: a cell's maximum covers
-// every slot of the cell, whether the published ROI maps it or not.
+// cells of S^3 slots (S = 8 or 4, by LOD); `raw` holds the largest |value| stored in a cell, `blk` the largest
+// raw value of the 2 x 2 x 2 block of cells that STARTS at the cell (on the ring torus).  Both are maintained
+// here, on the upload stream, right behind every scatter: the march reads only `blk`.  Conservative by
+// construction: a cell's maximum covers every slot of the cell, whether the published ROI maps it or not.
 // ---------------------------------------------------------------------------------------------------
 struct CellArgs {
-    const void* ring; void* raw; void* dil;
-    int32_t ring_dims[3];      // slots (x, y, z), each a multiple of 8
+    const void* ring; void* raw; void* blk;
+    int32_t ring_dims[3];      // slots (x, y, z), each a multiple of the cell size
     int32_t cdim[3];           // cells per axis
+    int32_t cshift;            // log2 of the cell size
     int32_t c0[3], cn[3];      // cell range to refresh (c0 may be negative / run past cdim: wraps on the torus)
 };
 
@@ -136,30 +137,31 @@ template <> __device__ __forceinline__ float cell_max<float>(float a, float b) {
 
 __device__ __forceinline__ int torus(int c, int n) { c %= n; return c < 0 ? c + n : c; }
 
-// one wave per cell: lane = (y, z) row of the cell, 8 slots along x each
+// 64 lanes per 8^3 cell (lane = one row of 8 slots) or per eight 4^3 cells... kept simple: one lane per row of
+// S slots; the S*S rows of a cell are S*S consecutive lanes (64 or 16), reduced with shuffles inside that group.
 template <typename T>
 __global__ __launch_bounds__(256) void cell_raw_kernel(const CellArgs a) {
-    const int cell = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
+    const int S = 1 << a.cshift, rows = S * S;               // 64 or 16 lanes per cell
+    const int t = (int)(blockIdx.x * 256u + threadIdx.x);
+    const int cell = t / rows, r = t % rows;
     const int total = a.cn[0] * a.cn[1] * a.cn[2];
-    if (cell >= total) return;
-    const int cx = torus(a.c0[0] + cell % a.cn[0], a.cdim[0]);
-    const int cy = torus(a.c0[1] + (cell / a.cn[0]) % a.cn[1], a.cdim[1]);
-    const int cz = torus(a.c0[2] + cell / (a.cn[0] * a.cn[1]), a.cdim[2]);
-    const size_t row = ((size_t)(cz * 8 + (lane >> 3)) * (size_t)a.ring_dims[1] + (size_t)(cy * 8 + (lane & 7))) *
-                           (size_t)a.ring_dims[0] + (size_t)cx * 8;
+    const bool live = cell < total;
+    const int cc = live ? cell : 0;
+    const int cx = torus(a.c0[0] + cc % a.cn[0], a.cdim[0]);
+    const int cy = torus(a.c0[1] + (cc / a.cn[0]) % a.cn[1], a.cdim[1]);
+    const int cz = torus(a.c0[2] + cc / (a.cn[0] * a.cn[1]), a.cdim[2]);
+    const size_t row = ((size_t)(cz * S + r / S) * (size_t)a.ring_dims[1] + (size_t)(cy * S + r % S)) *
+                           (size_t)a.ring_dims[0] + (size_t)cx * S;
     const T* p = static_cast<const T*>(a.ring) + row;
     T m = cell_abs(p[0]);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) m = cell_max(m, cell_abs(p[k]));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = cell_max(m, (T)__shfl_xor(m, d, 64));      // (integer types travel as int)
-    if (lane == 0) static_cast<T*>(a.raw)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
+    for (int k = 1; k < S; ++k) m = cell_max(m, cell_abs(p[k]));
+    for (int d = rows >> 1; d >= 1; d >>= 1) m = cell_max(m, (T)__shfl_xor(m, d, 64));      // (integer types travel as int)
+    if (live && r == 0) static_cast<T*>(a.raw)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
 }
 
-// one thread per cell of the range: maximum over the 3 x 3 x 3 raw neighbourhood on the torus
+// one thread per cell of the range: maximum over the 2 x 2 x 2 raw cells starting at the cell, on the torus
 template <typename T>
-__global__ __launch_bounds__(256) void cell_dilate_kernel(const CellArgs a) {
+__global__ __launch_bounds__(256) void cell_block_kernel(const CellArgs a) {
     const int cell = (int)(blockIdx.x * 256u + threadIdx.x);
     const int total = a.cn[0] * a.cn[1] * a.cn[2];
     if (cell >= total) return;
@@ -168,13 +170,13 @@ __global__ __launch_bounds__(256) void cell_dilate_kernel(const CellArgs a) {
     const int cz = torus(a.c0[2] + cell / (a.cn[0] * a.cn[1]), a.cdim[2]);
     const T* raw = static_cast<const T*>(a.raw);
     T m = raw[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx];
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
+    for (int dz = 0; dz <= 1; ++dz)
+        for (int dy = 0; dy <= 1; ++dy)
+            for (int dx = 0; dx <= 1; ++dx) {
                 const int x = torus(cx + dx, a.cdim[0]), y = torus(cy + dy, a.cdim[1]), z = torus(cz + dz, a.cdim[2]);
                 m = cell_max(m, raw[((size_t)z * a.cdim[1] + y) * a.cdim[0] + x]);
             }
-    static_cast<T*>(a.dil)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
+    static_cast<T*>(a.blk)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
 }
 
 struct GatherArgs {
@@ -323,33 +325,34 @@ hipError_t svr_launch_untile_grid(const void* gathered, void* frame_out, int fra
     return hipGetLastError();
 }
 
-// Refresh the macro-cell maxima of the cells a scatter into [off, off + shape) of the ring has touched (raw),
-// and of those cells' neighbours (dilated).  No-op for LODs without a cell grid (ring extents not multiples of 8).
-hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t ring_dims[3], void* raw, void* dil,
-                                  const int32_t cdim[3], const int32_t off[3], const int32_t shape[3], hipStream_t stream) {
-    if (!raw || !dil || shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return hipSuccess;
+// Refresh the macro-cell maxima of the cells a scatter into [off, off + shape) of the ring has touched (raw), and
+// of the 2 x 2 x 2 blocks those cells belong to.  No-op for LODs without a cell grid.
+hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t ring_dims[3], void* raw, void* blk,
+                                  const int32_t cdim[3], int cshift, const int32_t off[3], const int32_t shape[3],
+                                  hipStream_t stream) {
+    if (!raw || !blk || shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return hipSuccess;
     CellArgs a;
-    a.ring = ring; a.raw = raw; a.dil = dil;
+    a.ring = ring; a.raw = raw; a.blk = blk; a.cshift = cshift;
     for (int i = 0; i < 3; ++i) {
         a.ring_dims[i] = ring_dims[i]; a.cdim[i] = cdim[i];
-        a.c0[i] = off[i] >> 3;
-        a.cn[i] = ((off[i] + shape[i] - 1) >> 3) - a.c0[i] + 1;
+        a.c0[i] = off[i] >> cshift;
+        a.cn[i] = ((off[i] + shape[i] - 1) >> cshift) - a.c0[i] + 1;
     }
-    const int total = a.cn[0] * a.cn[1] * a.cn[2];
-    const dim3 g1((unsigned)((total + 3) / 4)), block(256);
+    const long long lanes = (long long)a.cn[0] * a.cn[1] * a.cn[2] << (2 * cshift);
+    const dim3 g1((unsigned)((lanes + 255) / 256)), block(256);
     if (storage == SVR_U8)       hipLaunchKernelGGL((cell_raw_kernel<uint8_t>), g1, block, 0, stream, a);
     else if (storage == SVR_U16) hipLaunchKernelGGL((cell_raw_kernel<uint16_t>), g1, block, 0, stream, a);
     else                         hipLaunchKernelGGL((cell_raw_kernel<float>), g1, block, 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    for (int i = 0; i < 3; ++i) {                  // one cell further out on every side, at most the whole torus
+    for (int i = 0; i < 3; ++i) {                  // the blocks that contain a refreshed cell start one cell earlier
         a.c0[i] -= 1;
-        a.cn[i] = a.cn[i] + 2 > a.cdim[i] ? a.cdim[i] : a.cn[i] + 2;
+        a.cn[i] = a.cn[i] + 1 > a.cdim[i] ? a.cdim[i] : a.cn[i] + 1;
     }
     const int total2 = a.cn[0] * a.cn[1] * a.cn[2];
     const dim3 g2((unsigned)((total2 + 255) / 256));
-    if (storage == SVR_U8)       hipLaunchKernelGGL((cell_dilate_kernel<uint8_t>), g2, block, 0, stream, a);
-    else if (storage == SVR_U16) hipLaunchKernelGGL((cell_dilate_kernel<uint16_t>), g2, block, 0, stream, a);
-    else                         hipLaunchKernelGGL((cell_dilate_kernel<float>), g2, block, 0, stream, a);
+    if (storage == SVR_U8)       hipLaunchKernelGGL((cell_block_kernel<uint8_t>), g2, block, 0, stream, a);
+    else if (storage == SVR_U16) hipLaunchKernelGGL((cell_block_kernel<uint16_t>), g2, block, 0, stream, a);
+    else                         hipLaunchKernelGGL((cell_block_kernel<float>), g2, block, 0, stream, a);
     return hipGetLastError();
 }

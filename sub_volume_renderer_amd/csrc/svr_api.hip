@@ -109,12 +109,15 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
         c->lod[l].labels = c->labels_all + c->lod_base_bytes[l];
     }
-    {   // macro-cell maxima (empty-space skipping): one grid of 8^3-slot cells per LOD whose extents allow it
+    {   // macro-cell maxima (empty-space skipping): one grid of cells per LOD whose extents are multiples of 8.
+        // The finest level gets 8^3-slot cells, the coarser ones 4^3: their structures are half / a quarter the size
+        // in slots, and a ray advances less per iteration there, so the finer grid costs no extra tests.
         size_t cells = 0;
         for (int l = 0; l < num_lods; ++l) {
             LodStorage& L = c->lod[l];
             L.cells_raw = L.cells_dil = nullptr; L.cell_base = 0;
-            for (int a = 0; a < 3; ++a) L.cdim[a] = L.ring[a] / 8;
+            L.cshift = l == 0 ? 3 : 2;
+            for (int a = 0; a < 3; ++a) L.cdim[a] = L.ring[a] >> L.cshift;
             if ((L.ring[0] | L.ring[1] | L.ring[2]) & 7) continue;
             L.cell_base = cells;
             cells += ((size_t)L.cdim[0] * L.cdim[1] * L.cdim[2] + 63) & ~(size_t)63;
@@ -315,7 +318,7 @@ static hipError_t scatter_into_ring(svr_ctx* c, int lod, const ScatterArgs& a, b
     hipError_t e = svr_launch_scatter(a, c->upload_stream);
     const LodStorage& L = c->lod[lod];
     if (e == hipSuccess && wrote_density && L.cells_raw)
-        e = svr_launch_cell_update(L.density, c->density_storage, L.ring, L.cells_raw, L.cells_dil, L.cdim,
+        e = svr_launch_cell_update(L.density, c->density_storage, L.ring, L.cells_raw, L.cells_dil, L.cdim, L.cshift,
                                    a.dst_off, a.shape, c->upload_stream);
     return e;
 }
@@ -690,6 +693,11 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.slab_long = (c->variant & 4) ? 0 : 1;
     static const bool brick_pow2 = getenv("SVR_BRICK_POW2") != nullptr;       // A/B measurements only
     P.brick_pow2 = brick_pow2 ? 1 : 0;
+    // LDS per wave: 8 KiB holds the box of a 16..64-iteration slab of byte voxels and lets 20 one-wave blocks share
+    // a CU's 160 KiB.  2- and 4-byte voxels fit shorter slabs in the same 8 KiB; 16 KiB for them (10 waves per CU)
+    // measured slower: K1 full, f32 rings 1.60 ms against 1.31 ms (SVR_BRICK_BYTES: experiments)
+    static const int brick_bytes_env = getenv("SVR_BRICK_BYTES") ? atoi(getenv("SVR_BRICK_BYTES")) : 0;
+    P.brick_bytes = brick_bytes_env >= 1024 && brick_bytes_env <= 65536 ? (brick_bytes_env & ~15) : 8192;
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
         float wx[4];
@@ -737,15 +745,22 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             // iteration); rows in 16-byte groups, indices below 2^15 for the packed (y, z) brick address
             const float smax = fmaxf(Q.scale[0], fmaxf(Q.scale[1], Q.scale[2]));
             const int slab = smax > 0.75f ? 16 : (smax > 0.375f ? 32 : 64);
-            bool ok = c->density_u8 && (Q.ring[0] & 15u) == 0u && (brick_mask >> l & 1);
+            // (ring rows must be whole 16-byte groups: 16 / 8 / 4 voxels for u8 / u16 / f32 rings)
+            bool ok = ((Q.ring[0] * des) & 15u) == 0u && (brick_mask >> l & 1);
             for (int a = 0; a < 3; ++a) ok = ok && (long long)Q.off[a] + (long long)Q.shape[a] < 32768;
             Q.slab = ok ? slab : 0;
-            // empty-space skipping: one test of the dilated cell under a sample vouches for the next
-            // `skip_batches` batches of 8 iterations (the lane's travel over them must stay under one cell: checked
-            // per lane in the kernel); coarser LODs advance less per iteration
+            // empty-space skipping: cell tests every `skip_batches` batches of 8 iterations, such that a ray
+            // (0.8 voxels of the finest level per iteration, fs_main.wgsl:20) travels at most one cell between two
+            // tests on every axis (checked again per lane in the kernel): 8^3 cells at scale 1 and 4^3 cells at scale
+            // 1/2 -> every batch; 4^3 cells at scale 1/4 -> every other batch
             Q.cell_base = (uint32_t)(L.cell_base * des);
-            Q.cdim[0] = (uint32_t)L.cdim[0]; Q.cdim[1] = (uint32_t)L.cdim[1];
-            Q.skip_batches = (L.cells_dil && P.lod_pow2[l]) ? slab / 16 : 0;
+            for (int a = 0; a < 3; ++a) Q.cdim[a] = (uint32_t)L.cdim[a];
+            Q.cshift = L.cshift;
+            Q.skip_batches = 0;
+            if (L.cells_dil && P.lod_pow2[l]) {
+                const float room = (float)(1 << L.cshift) - 0.5f, per_batch = smax * 8.0f * P.rel_step;
+                Q.skip_batches = per_batch * 4.0f <= room ? 4 : (per_batch * 2.0f <= room ? 2 : (per_batch <= room ? 1 : 0));
+            }
         }
     }
     // skip only when some texel value can reach the threshold and not every one does: threshold = +inf (or NaN)
@@ -753,6 +768,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     const bool skip = c->cells_dil_all && !(c->variant & 8) && P.lmip_threshold_raw > 0u &&
                       (c->density_storage == SVR_F32 ? (m.lmip_threshold > 0.0f && m.lmip_threshold < INFINITY)
                                                      : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u));
+    static const int skip_flags_env = getenv("SVR_SKIP_FLAGS") ? atoi(getenv("SVR_SKIP_FLAGS")) : 1;      // A/B measurements
+    P.skip_flags = skip_flags_env;
     P.cells_all = skip ? c->cells_dil_all : nullptr;
     P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;
     P.density_all = c->density_all;

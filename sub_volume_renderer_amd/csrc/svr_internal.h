@@ -31,10 +31,11 @@ struct LodParams {
     uint32_t rx4;              // row pitch of the density ring in bytes (ring[0] * element size)
     float    ss[3];            // size * scale (the fused per-axis factor of the fast paths when scale = 2^-k)
     int32_t  slab;             // brick slab length in iterations (0: this LOD never stages bricks)
-    // empty-space skipping: the dilated macro-cell maxima of this LOD inside MarchParams::cells_all
+    // empty-space skipping: the 2x2x2-block maxima of this LOD's macro cells inside MarchParams::cells_all
     uint32_t cell_base;        // byte offset of the LOD's cell grid
-    uint32_t cdim[2];          // cells along x and y
-    int32_t  skip_batches;     // batches of 8 iterations one cell test vouches for (0: never skip on this LOD)
+    uint32_t cdim[3];          // cells per axis
+    int32_t  cshift;           // log2 of the cell size (3 or 2)
+    int32_t  skip_batches;     // batches of 8 iterations between two cell tests (0: never skip on this LOD)
 };
 
 struct MarchParams {
@@ -80,6 +81,8 @@ struct MarchParams {
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
     int32_t slab_long;             // 1: brick slabs start at twice their plain length
+    int32_t skip_flags;            // empty-space skipping policy bits (1: short march while lanes only follow a maximum)
+    int32_t brick_bytes;           // LDS bytes per wave for brick staging (also what caps the waves per CU: 160 KiB / it)
     int32_t brick_pow2;            // A/B: round the brick row pitch up to a power of two (the round-1 layout)
     int32_t block_waves_log2;      // span kernel: block = (1 << this)^2 wave tiles (0: one wave per block)
     const uint32_t* tile_order;    // blockIdx -> tile index (null: contiguous run of tiles per XCD)
@@ -98,10 +101,11 @@ struct LodStorage {
     void*     density;
     uint32_t* labels;
     svr_lod_state state;
-    // macro-cell maxima (8^3 slots per cell) for empty-space skipping; null when an extent is not a multiple of 8
+    // macro-cell maxima (8^3 or 4^3 slots per cell) for empty-space skipping; null when an extent is not a multiple of 8
     void*     cells_raw;
-    void*     cells_dil;
+    void*     cells_dil;       // maxima over the 2 x 2 x 2 block of cells starting at each cell
     int32_t   cdim[3];
+    int32_t   cshift;          // log2 of the cell size
     size_t    cell_base;       // element offset of this LOD's grid inside svr_ctx::cells_dil_all
 };
 
@@ -204,8 +208,9 @@ struct ScatterArgs {
     int32_t shape[3];
 };
 hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream);
-hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t ring_dims[3], void* raw, void* dil,
-                                  const int32_t cdim[3], const int32_t off[3], const int32_t shape[3], hipStream_t stream);
+hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t ring_dims[3], void* raw, void* blk,
+                                  const int32_t cdim[3], int cshift, const int32_t off[3], const int32_t shape[3],
+                                  hipStream_t stream);
 hipError_t svr_launch_gather(const void* ring_density, int ring_storage, const uint32_t* ring_labels, const int32_t ring[3],
                              const int32_t off[3], const int32_t shape[3],
                              float* out_density, uint32_t* out_labels, hipStream_t stream);

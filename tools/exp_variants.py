@@ -49,5 +49,5 @@ for camname in cams:
             for iters in (10, 10):      # first pass = warm-up (clocks, caches)
                 N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)), "time")
             print(f"{camname:5s} {mode:5s} variant={v:#06x} steps={steps/1e6:8.1f}M {ms.value:7.3f} ms {steps/ms.value/1e6:7.1f} Gsteps/s "
-                  f"{4*steps/ms.value/1e6/8000*100:5.1f}% {same} census[gen,dir,brick,slabs,runs,zero,waves]={census[:7]}", flush=True)
+                  f"{4*steps/ms.value/1e6/8000*100:5.1f}% {same} census[gen,dir,brick,slabs,runs,zero,waves,skipped]={census[:8]}", flush=True)
     del scene, vol
