@@ -157,6 +157,9 @@ def summarise(ms):
 
 def main():
     args = parse()
+    # OpenMP threads of the host-side helpers (the lazy volume's block generator, the oracle) sleep between parallel
+    # regions instead of spinning: a spinning team beside the render loop burns the process's CPU quota
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     import numpy as np
     import torch
     import torch.distributed as dist

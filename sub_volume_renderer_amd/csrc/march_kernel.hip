@@ -417,10 +417,11 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 // (v_pk_mul_f32 / v_pk_add_f32 are IEEE-exact per component, no fusing): per axis
 //   ic = i32((start + f32(i) * step) * ss),   ss = size * scale (scale = 2^-k, see the caller)
 struct Idx2 { uint32_t x0, y0, z0, x1, y1, z1; };
-__device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float2_t iter, float ssx, float ssy, float ssz) {
-    const float2_t cx = (iter * R.step.x + R.start.x) * ssx;     // -ffp-contract=off: mul, add, mul
-    const float2_t cy = (iter * R.step.y + R.start.y) * ssy;
-    const float2_t cz = (iter * R.step.z + R.start.z) * ssz;
+__device__ __forceinline__ Idx2 voxel_pair(float sx, float sy, float sz, float tx, float ty, float tz, float2_t iter,
+                                           float ssx, float ssy, float ssz) {
+    const float2_t cx = (iter * tx + sx) * ssx;                  // -ffp-contract=off: mul, add, mul
+    const float2_t cy = (iter * ty + sy) * ssy;
+    const float2_t cz = (iter * tz + sz) * ssz;
     Idx2 r;
     r.x0 = (uint32_t)(int)cx.x; r.x1 = (uint32_t)(int)cx.y;
     r.y0 = (uint32_t)(int)cy.x; r.y1 = (uint32_t)(int)cy.y;
@@ -432,10 +433,11 @@ __device__ __forceinline__ Idx2 voxel_pair(const Ray& R, float2_t iter, float ss
 // the upper half of the register directly): operand of the v_dot2_u32_u16 brick address below.
 // Indices are < 2^15 here (checked by the caller through the packed-i16 box reduction).
 struct Idx2p { uint32_t x0, yz0, x1, yz1; };
-__device__ __forceinline__ Idx2p voxel_pair_packed(const Ray& R, float2_t iter, float ssx, float ssy, float ssz) {
-    const float2_t cx = (iter * R.step.x + R.start.x) * ssx;
-    const float2_t cy = (iter * R.step.y + R.start.y) * ssy;
-    const float2_t cz = (iter * R.step.z + R.start.z) * ssz;
+__device__ __forceinline__ Idx2p voxel_pair_packed(float sx, float sy, float sz, float tx, float ty, float tz, float2_t iter,
+                                                   float ssx, float ssy, float ssz) {
+    const float2_t cx = (iter * tx + sx) * ssx;
+    const float2_t cy = (iter * ty + sy) * ssy;
+    const float2_t cz = (iter * tz + sz) * ssz;
     Idx2p r;
     r.x0 = (uint32_t)(int)cx.x; r.x1 = (uint32_t)(int)cx.y;
     r.yz0 = (uint32_t)(int)cy.x; r.yz1 = (uint32_t)(int)cy.y;
@@ -513,6 +515,8 @@ struct LodK {
     uint32_t rx4, base_bytes;
     float    ss[3];
     int32_t  slab;
+    const void* rbase;
+    uint32_t rbytes;
 };
 __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     LodK k;
@@ -521,6 +525,7 @@ __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
         k.ring[a] = p->lod[l].ring[a]; k.scale[a] = p->lod[l].scale[a]; k.addw[a] = p->lod[l].addw[a]; k.ss[a] = p->lod[l].ss[a];
     }
     k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
+    k.rbase = p->lod[l].rbase; k.rbytes = p->lod[l].rbytes;
     return k;
 }
 
@@ -532,7 +537,7 @@ struct LodEvents {
 
 // LDS bricks: one private region of MarchParams::brick_bytes per wave (dynamic LDS, see launch_nl)
 
-template <int NL, int U, bool COUNT, int ESH>
+template <int NL, int U, bool COUNT, int ESH, bool BIG>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // dynamic LDS: kBrickBytes per wave of the block (u8 rings), see launch_nl
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
@@ -579,19 +584,14 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     };
 
     // (the ray lives in registers: it is assembled from selects, never written through a pointer under a branch)
-#ifdef SVR_EXP_OLD_RAY
-    Ray R;
-    R.nsteps = 0; R.start = { 0.f, 0.f, 0.f }; R.step = { 0.f, 0.f, 0.f };
-    const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
-    const int nsteps = frag ? R.nsteps : 0;
-#else
+    // (the ray lives in six scalar registers, assembled from selects: a struct written through a pointer under a
+    // branch ends up in private memory as soon as the register allocator is under pressure)
     Ray Rs;
     Rs.nsteps = 0; Rs.start = { 0.f, 0.f, 0.f }; Rs.step = { 0.f, 0.f, 0.f };
     const bool frag = inside && (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, Rs);
     const int nsteps = frag ? Rs.nsteps : 0;
-    const Ray R = { { frag ? Rs.start.x : 0.f, frag ? Rs.start.y : 0.f, frag ? Rs.start.z : 0.f },
-                    { frag ? Rs.step.x : 0.f, frag ? Rs.step.y : 0.f, frag ? Rs.step.z : 0.f }, nsteps };
-#endif
+    const float Rsx = frag ? Rs.start.x : 0.f, Rsy = frag ? Rs.start.y : 0.f, Rsz = frag ? Rs.start.z : 0.f;
+    const float Rtx = frag ? Rs.step.x : 0.f, Rty = frag ? Rs.step.y : 0.f, Rtz = frag ? Rs.step.z : 0.f;
 
     // ---- exact per-LOD event iterations
     // ic is monotone along the ray, so its values at the first and last sample bound every other
@@ -600,9 +600,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     float d0[3], d1[3];                       // data coords (sample_vol.wgsl:6) of samples 0 and nsteps-1
     {
         const float lastf = (float)(nsteps - 1);
-        d0[0] = (R.start.x + 0.0f * R.step.x) * P.size[0];  d1[0] = (R.start.x + lastf * R.step.x) * P.size[0];
-        d0[1] = (R.start.y + 0.0f * R.step.y) * P.size[1];  d1[1] = (R.start.y + lastf * R.step.y) * P.size[1];
-        d0[2] = (R.start.z + 0.0f * R.step.z) * P.size[2];  d1[2] = (R.start.z + lastf * R.step.z) * P.size[2];
+        d0[0] = (Rsx + 0.0f * Rtx) * P.size[0];  d1[0] = (Rsx + lastf * Rtx) * P.size[0];
+        d0[1] = (Rsy + 0.0f * Rty) * P.size[1];  d1[1] = (Rsy + lastf * Rty) * P.size[1];
+        d0[2] = (Rsz + 0.0f * Rtz) * P.size[2];  d1[2] = (Rsz + lastf * Rtz) * P.size[2];
     }
     LodEvents ev[NL];
 #pragma unroll
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         }
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const float st = ax == 0 ? R.start.x : (ax == 1 ? R.start.y : R.start.z);
-            const float sp = ax == 0 ? R.step.x : (ax == 1 ? R.step.y : R.step.z);
+            const float st = ax == 0 ? Rsx : (ax == 1 ? Rsy : Rsz);
+            const float sp = ax == 0 ? Rtx : (ax == 1 ? Rty : Rtz);
             const bool inc = sp > 0.0f;
             const int v0 = (int)(d0[ax] * L.scale[ax]), v1 = (int)(d1[ax] * L.scale[ax]);   // ic(0), ic(nsteps-1)
             // == first_cross(nsteps, st, sp, size, scale, T): pred(0) -> 0; !pred(nsteps-1) -> nsteps
@@ -651,7 +651,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         ev[l].a = a; ev[l].b = b; ev[l].cx = cr[0]; ev[l].cy = cr[1]; ev[l].cz = cr[2];
     }
 
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    // One buffer resource over the allocation that holds every LOD's ring (32-bit byte offsets, hardware range
+    // check) while it is below 4 GiB; BIG builds (rings of 4 GiB or more in total) take one resource per LOD instead.
+    __amdgpu_buffer_rsrc_t rsrc_all = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
 
     bool found = false, finished = (P.dbg_nowait & 2) != 0;    // instruction-count experiments: prologue + epilogue only
@@ -710,9 +712,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     int brick_mode = 0;                              // wave-uniform: 0 gathers only, k > 0 brick slabs of 2^(k-1) times the plain length
     if (P.brick) {
         const float pf = (float)min(max(nsteps - 1, 0), 256);
-        const int qx = (int)((R.start.x + pf * R.step.x) * P.size[0]) >> (7 - ESH);   // 128 bytes per line
-        const int qy = (int)((R.start.y + pf * R.step.y) * P.size[1]);
-        const int qz = (int)((R.start.z + pf * R.step.z) * P.size[2]);
+        const int qx = (int)((Rsx + pf * Rtx) * P.size[0]) >> (7 - ESH);   // 128 bytes per line
+        const int qy = (int)((Rsy + pf * Rty) * P.size[1]);
+        const int qz = (int)((Rsz + pf * Rtz) * P.size[2]);
         const int key = frag ? ((qz * 4099 + qy) * 64 + (qx & 63)) : -1 - lane;
         const int k0 = __builtin_amdgcn_update_dpp(key, key, 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
         const int k1 = __builtin_amdgcn_update_dpp(key, key, 0x55, 0xF, 0xF, false);   // [1,1,1,1]
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         code = l;
                         E = min(E, ev[l].b);
                         // wrap constants in force at iteration n, and when they change next
-                        const bool px = (n >= ev[l].cx) == (R.step.x > 0.0f);   // slot = ic + addw - ring ?
-                        const bool py = (n >= ev[l].cy) == (R.step.y > 0.0f);
-                        const bool pz = (n >= ev[l].cz) == (R.step.z > 0.0f);
+                        const bool px = (n >= ev[l].cx) == (Rtx > 0.0f);   // slot = ic + addw - ring ?
+                        const bool py = (n >= ev[l].cy) == (Rty > 0.0f);
+                        const bool pz = (n >= ev[l].cz) == (Rtz > 0.0f);
                         const uint32_t kx = (uint32_t)L.addw[0] - (px ? L.ring[0] : 0u);
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
@@ -783,28 +785,57 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // ---- general batch: each sample evaluated exactly (intervals + explicit ring wrap)
             const kparams_t Pg = fresh_params(P);
             texel_t s[U];
-            uint32_t off[U];
             const float basef = (float)n;
+            if constexpr (!BIG) {
+                // all rings in one buffer resource: one load per sample serves the lanes of every LOD
+                uint32_t off[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                off[u] = 0xFFFFFFFFu;
-                const float iter = basef + (float)u;
-                const float dx = (R.start.x + iter * R.step.x) * Pg->size[0];
-                const float dy = (R.start.y + iter * R.step.y) * Pg->size[1];
-                const float dz = (R.start.z + iter * R.step.z) * Pg->size[2];
-                bool done = !alive || (n + u) >= nsteps;
+                for (int u = 0; u < U; ++u) {
+                    off[u] = 0xFFFFFFFFu;
+                    const float iter = basef + (float)u;
+                    const float dx = (Rsx + iter * Rtx) * Pg->size[0];
+                    const float dy = (Rsy + iter * Rty) * Pg->size[1];
+                    const float dz = (Rsz + iter * Rtz) * Pg->size[2];
+                    bool done = !alive || (n + u) >= nsteps;
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
-                    if (__builtin_amdgcn_ballot_w64(sel) != 0) {
-                        const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz);
-                        off[u] = sel ? ofs : off[u];
+                    for (int l = 0; l < NL; ++l) {
+                        const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
+                        if (__builtin_amdgcn_ballot_w64(sel) != 0) {
+                            const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz);
+                            off[u] = sel ? ofs : off[u];
+                        }
+                        done = done || sel;
                     }
-                    done = done || sel;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc_all, off[u]);
+            } else {
+                // rings of 4 GiB or more in total: each LOD has a buffer resource of its own, so the lanes of a
+                // sample are served LOD by LOD (the range check makes the other lanes read nothing)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float iter = basef + (float)u;
+                    const float dx = (Rsx + iter * Rtx) * Pg->size[0];
+                    const float dy = (Rsy + iter * Rty) * Pg->size[1];
+                    const float dz = (Rsz + iter * Rtz) * Pg->size[2];
+                    bool done = !alive || (n + u) >= nsteps;
+                    texel_t acc = 0;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
+                        if (__builtin_amdgcn_ballot_w64(sel) != 0) {
+                            const LodK Lg = load_lod(Pg, l);
+                            const uint32_t ofs = lod_offset_wrapped<ESH>(Lg, dx, dy, dz);
+                            __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<void*>(Lg.rbase), 0, (int)Lg.rbytes, 0x00020000);
+                            const texel_t t = fetch_density<ESH>(rl, sel ? ofs : 0xFFFFFFFFu);
+                            acc = sel ? t : acc;
+                        }
+                        done = done || sel;
+                    }
+                    s[u] = acc;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
             lmip_batch(s, n, alive, true);
             n += U;
             lap(2);
@@ -833,6 +864,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // scale is 2^-k here, so (coord*size)*scale == coord*(size*scale) bit for bit (scaling by a
             // power of two commutes with rounding): one multiply per axis instead of two
             const float ssx = L.ss[0], ssy = L.ss[1], ssz = L.ss[2];      // size * scale, multiplied on the host
+            // the buffer resource this LOD's texels come through (hardware range check returns 0 beyond it)
+            __amdgpu_buffer_rsrc_t rsrc = rsrc_all;
+            if constexpr (BIG) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.rbase), 0, (int)L.rbytes, 0x00020000);
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
             // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
@@ -853,7 +887,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 if (sb > 0 && run >= 4 * sb) {
                     const float reach = (float)(8 * sb);
                     const uint32_t cs = (uint32_t)Ps->lod[first].cshift;
-                    const bool slow = fmaxf(fmaxf(fabsf(R.step.x * ssx), fabsf(R.step.y * ssy)), fabsf(R.step.z * ssz)) * reach <=
+                    const bool slow = fmaxf(fmaxf(fabsf(Rtx * ssx), fabsf(Rty * ssy)), fabsf(Rtz * ssz)) * reach <=
                                       (float)(1u << cs) - 0.5f;
                     __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<void*>(Ps->cells_all), 0, (int)Ps->cells_all_bytes, 0x00020000);
@@ -872,7 +906,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         for (int g = 0; g < 6; g += 2) {
                             const float i0 = (float)n + reach * (float)g;
                             const float2_t iter = { fminf(i0, lastf), fminf(i0 + reach, lastf) };
-                            const Idx2 q = voxel_pair(R, iter, ssx, ssy, ssz);
+                            const Idx2 q = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                             px[g] = (q.x0 + (uint32_t)L.addw[0]) >> cs; py[g] = (q.y0 + (uint32_t)L.addw[1]) >> cs; pz[g] = (q.z0 + (uint32_t)L.addw[2]) >> cs;
                             if (g + 1 < 5) {
                                 px[g + 1] = (q.x1 + (uint32_t)L.addw[0]) >> cs; py[g + 1] = (q.y1 + (uint32_t)L.addw[1]) >> cs;
@@ -928,9 +962,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const bool live = alive && !finished && n < nsteps;
                     // first and last existing sample of the slab, both at once with the packed chain
                     const float2_t it = { (float)n, (float)min(n + slab - 1, nsteps - 1) };
-                    const float2_t ex = (it * R.step.x + R.start.x) * ssx;
-                    const float2_t ey = (it * R.step.y + R.start.y) * ssy;
-                    const float2_t ez = (it * R.step.z + R.start.z) * ssz;
+                    const float2_t ex = (it * Rtx + Rsx) * ssx;
+                    const float2_t ey = (it * Rty + Rsy) * ssy;
+                    const float2_t ez = (it * Rtz + Rsz) * ssz;
                     // exact box of the wave's samples: min / max per axis over the live lanes
                     const int big = 0x7fffffff;
                     int lx = live ? min((int)ex.x, (int)ex.y) : big, hx = live ? max((int)ex.x, (int)ex.y) : -big;
@@ -998,7 +1032,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         float2_t iter = { (float)n, (float)n + 1.0f };
 #pragma unroll
                         for (int u = 0; u < U; u += 2) {
-                            const Idx2p v = voxel_pair_packed(R, iter, ssx, ssy, ssz);
+                            const Idx2p v = voxel_pair_packed(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                             iter += 2.0f;
                             const uint32_t a0 = dot2_u16(v.yz0, kyz, shl_add_c<ESH>(v.x0, bk));
                             const uint32_t a1 = dot2_u16(v.yz1, kyz, shl_add_c<ESH>(v.x1, bk));
@@ -1034,7 +1068,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 float2_t iter = { (float)n, (float)n + 1.0f };
 #pragma unroll
                 for (int u = 0; u < U; u += 2) {
-                    const Idx2 v = voxel_pair(R, iter, ssx, ssy, ssz);
+                    const Idx2 v = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                     iter += 2.0f;
                     off[u] = mad24(mad24(v.z0, L.ring[1], v.y0), L.rx4, shl_add_c<ESH>(v.x0, Kc));
                     off[u + 1] = mad24(mad24(v.z1, L.ring[1], v.y1), L.rx4, shl_add_c<ESH>(v.x1, Kc));
@@ -1064,8 +1098,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     Hit h;
     h.found = found; h.sample = samp; h.steps = steps;
     const float hit_f = (float)hit_i;
-    h.offset = { hit_f * R.step.x, hit_f * R.step.y, hit_f * R.step.z };                    // raycast.wgsl:30
-    h.coord = { R.start.x + h.offset.x, R.start.y + h.offset.y, R.start.z + h.offset.z };   // :31
+    h.offset = { hit_f * Rtx, hit_f * Rty, hit_f * Rtz };                    // raycast.wgsl:30
+    h.coord = { Rsx + h.offset.x, Rsy + h.offset.y, Rsz + h.offset.z };   // :31
     if (inside) {
         // the epilogue re-reads its (cold) uniforms through a laundered kernarg pointer so that
         // they are not kept live in SGPRs across the march loop
@@ -1092,23 +1126,27 @@ template <int NL>
 hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
-    const bool simple = kind == 1 || p.density_all_bytes == 0;   // rings the 32-bit / 24-bit addressing of the span kernel cannot reach
+    const bool simple = kind == 1 || !p.span_ok;                 // rings the 32-bit / 24-bit addressing of the span kernel cannot reach
     if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {
         const int threads = 64 << (2 * p.block_waves_log2);
         const size_t lds = (size_t)p.brick_bytes * (threads / 64);
-        if (p.density_esh == 0) {
-            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
-            else         hipLaunchKernelGGL((march_span<NL, 8, false, 0>), dim3(nblocks), dim3(threads), lds, stream, p);
-        } else if (p.density_esh == 1) {
-            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 1>), dim3(nblocks), dim3(threads), lds, stream, p);
-            else         hipLaunchKernelGGL((march_span<NL, 8, false, 1>), dim3(nblocks), dim3(threads), lds, stream, p);
-        } else {
-            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, 2>), dim3(nblocks), dim3(threads), lds, stream, p);
-            else         hipLaunchKernelGGL((march_span<NL, 8, false, 2>), dim3(nblocks), dim3(threads), lds, stream, p);
-        }
+#define SVR_LAUNCH_SPAN(ESH_)                                                                                              \
+    do {                                                                                                                   \
+        if (p.per_lod_rsrc) {                                                                                              \
+            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, ESH_, true>), dim3(nblocks), dim3(threads), lds, stream, p);   \
+            else         hipLaunchKernelGGL((march_span<NL, 8, false, ESH_, true>), dim3(nblocks), dim3(threads), lds, stream, p);  \
+        } else {                                                                                                           \
+            if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, ESH_, false>), dim3(nblocks), dim3(threads), lds, stream, p);  \
+            else         hipLaunchKernelGGL((march_span<NL, 8, false, ESH_, false>), dim3(nblocks), dim3(threads), lds, stream, p); \
+        }                                                                                                                  \
+    } while (0)
+        if (p.density_esh == 0) SVR_LAUNCH_SPAN(0);
+        else if (p.density_esh == 1) SVR_LAUNCH_SPAN(1);
+        else SVR_LAUNCH_SPAN(2);
+#undef SVR_LAUNCH_SPAN
     }
     return hipGetLastError();
 }

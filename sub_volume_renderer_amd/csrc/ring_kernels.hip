@@ -137,26 +137,29 @@ template <> __device__ __forceinline__ float cell_max<float>(float a, float b) {
 
 __device__ __forceinline__ int torus(int c, int n) { c %= n; return c < 0 ? c + n : c; }
 
-// 64 lanes per 8^3 cell (lane = one row of 8 slots) or per eight 4^3 cells... kept simple: one lane per row of
-// S slots; the S*S rows of a cell are S*S consecutive lanes (64 or 16), reduced with shuffles inside that group.
-template <typename T>
+// One thread per cell, S * S rows of S slots each; neighbouring threads take neighbouring cells along x, so a
+// wave's loads of one row index cover 64 * S contiguous slots of a ring row: coalesced, every byte read once.
+template <typename T, int S>
 __global__ __launch_bounds__(256) void cell_raw_kernel(const CellArgs a) {
-    const int S = 1 << a.cshift, rows = S * S;               // 64 or 16 lanes per cell
-    const int t = (int)(blockIdx.x * 256u + threadIdx.x);
-    const int cell = t / rows, r = t % rows;
+    const int cell = (int)(blockIdx.x * 256u + threadIdx.x);
     const int total = a.cn[0] * a.cn[1] * a.cn[2];
-    const bool live = cell < total;
-    const int cc = live ? cell : 0;
-    const int cx = torus(a.c0[0] + cc % a.cn[0], a.cdim[0]);
-    const int cy = torus(a.c0[1] + (cc / a.cn[0]) % a.cn[1], a.cdim[1]);
-    const int cz = torus(a.c0[2] + cc / (a.cn[0] * a.cn[1]), a.cdim[2]);
-    const size_t row = ((size_t)(cz * S + r / S) * (size_t)a.ring_dims[1] + (size_t)(cy * S + r % S)) *
-                           (size_t)a.ring_dims[0] + (size_t)cx * S;
-    const T* p = static_cast<const T*>(a.ring) + row;
-    T m = cell_abs(p[0]);
-    for (int k = 1; k < S; ++k) m = cell_max(m, cell_abs(p[k]));
-    for (int d = rows >> 1; d >= 1; d >>= 1) m = cell_max(m, (T)__shfl_xor(m, d, 64));      // (integer types travel as int)
-    if (live && r == 0) static_cast<T*>(a.raw)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
+    if (cell >= total) return;
+    const int cx = torus(a.c0[0] + cell % a.cn[0], a.cdim[0]);
+    const int cy = torus(a.c0[1] + (cell / a.cn[0]) % a.cn[1], a.cdim[1]);
+    const int cz = torus(a.c0[2] + cell / (a.cn[0] * a.cn[1]), a.cdim[2]);
+    typedef T row_t __attribute__((ext_vector_type(S)));            // one row of the cell: S * sizeof(T) bytes, aligned
+    T m = 0;
+    for (int z = 0; z < S; ++z) {
+        const T* plane = static_cast<const T*>(a.ring) +
+                         ((size_t)(cz * S + z) * (size_t)a.ring_dims[1] + (size_t)cy * S) * (size_t)a.ring_dims[0] + (size_t)cx * S;
+#pragma unroll
+        for (int y = 0; y < S; ++y) {
+            const row_t r = *reinterpret_cast<const row_t*>(plane + (size_t)y * (size_t)a.ring_dims[0]);
+#pragma unroll
+            for (int k = 0; k < S; ++k) m = cell_max(m, cell_abs((T)r[k]));
+        }
+    }
+    static_cast<T*>(a.raw)[((size_t)cz * a.cdim[1] + cy) * a.cdim[0] + cx] = m;
 }
 
 // one thread per cell of the range: maximum over the 2 x 2 x 2 raw cells starting at the cell, on the torus
@@ -338,11 +341,17 @@ hipError_t svr_launch_cell_update(const void* ring, int storage, const int32_t r
         a.c0[i] = off[i] >> cshift;
         a.cn[i] = ((off[i] + shape[i] - 1) >> cshift) - a.c0[i] + 1;
     }
-    const long long lanes = (long long)a.cn[0] * a.cn[1] * a.cn[2] << (2 * cshift);
-    const dim3 g1((unsigned)((lanes + 255) / 256)), block(256);
-    if (storage == SVR_U8)       hipLaunchKernelGGL((cell_raw_kernel<uint8_t>), g1, block, 0, stream, a);
-    else if (storage == SVR_U16) hipLaunchKernelGGL((cell_raw_kernel<uint16_t>), g1, block, 0, stream, a);
-    else                         hipLaunchKernelGGL((cell_raw_kernel<float>), g1, block, 0, stream, a);
+    const int total = a.cn[0] * a.cn[1] * a.cn[2];
+    const dim3 g1((unsigned)((total + 255) / 256)), block(256);
+#define SVR_CELL_RAW(T)                                                                            \
+    do {                                                                                           \
+        if (cshift == 3) hipLaunchKernelGGL((cell_raw_kernel<T, 8>), g1, block, 0, stream, a);      \
+        else             hipLaunchKernelGGL((cell_raw_kernel<T, 4>), g1, block, 0, stream, a);      \
+    } while (0)
+    if (storage == SVR_U8)       SVR_CELL_RAW(uint8_t);
+    else if (storage == SVR_U16) SVR_CELL_RAW(uint16_t);
+    else                         SVR_CELL_RAW(float);
+#undef SVR_CELL_RAW
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (int i = 0; i < 3; ++i) {                  // the blocks that contain a refreshed cell start one cell earlier

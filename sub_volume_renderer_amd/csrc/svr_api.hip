@@ -625,13 +625,14 @@ static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, in
     return SVR_OK;
 }
 
-// Can the span kernel address this context's rings (32-bit byte offsets into one allocation, 24-bit row
-// index and row pitch)?  Otherwise every render takes the straightforward kernel's 64-bit addressing.
+// Can the span kernel address this context's rings?  Every LOD's ring must stay below 4 GiB (32-bit byte offsets
+// into its buffer resource) and within the 24-bit row index and row pitch of the exact general path; otherwise
+// every render takes the straightforward kernel's 64-bit addressing.
 static bool span_addressable(const svr_ctx* c) {
-    if (c->density_all_bytes >= ((size_t)1 << 32)) return false;
     const uint64_t des = svr_dtype_size(c->density_storage);
     for (int l = 0; l < c->num_lods; ++l)
-        if ((uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
+        if ((uint64_t)c->lod[l].voxels * des + 64 >= ((uint64_t)1 << 32) ||
+            (uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
             (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
     return true;
 }
@@ -773,7 +774,18 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.cells_all = skip ? c->cells_dil_all : nullptr;
     P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;
     P.density_all = c->density_all;
-    P.density_all_bytes = span_addressable(c) ? (uint32_t)c->density_all_bytes : 0u;
+    P.span_ok = span_addressable(c) ? 1 : 0;
+    P.per_lod_rsrc = c->density_all_bytes >= ((size_t)1 << 32) ? 1 : 0;
+    P.density_all_bytes = P.per_lod_rsrc ? 0u : (uint32_t)c->density_all_bytes;
+    for (int l = 0; l < c->num_lods; ++l) {
+        LodParams& Q = P.lod[l];
+        if (P.per_lod_rsrc) {
+            Q.rbase = c->lod[l].density; Q.base_bytes = 0u;
+            Q.rbytes = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)c->lod[l].voxels * svr_dtype_size(c->density_storage) + 64);
+        } else {
+            Q.rbase = c->density_all; Q.rbytes = P.density_all_bytes;
+        }
+    }
     P.density_esh = c->density_storage == SVR_U8 ? 0 : (c->density_storage == SVR_U16 ? 1 : 2);
     return SVR_OK;
 }

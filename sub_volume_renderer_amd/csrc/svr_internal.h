@@ -26,12 +26,16 @@ struct LodParams {
     uint32_t wrap0[3];         // off - floor(off/ring)*ring  (ring slot of the ROI's first voxel)
     uint32_t ring[3];          // ring extent
     float    scale[3];         // scale_factor
-    uint32_t base_bytes;       // byte offset of this LOD's density ring inside MarchParams::density_all
+    uint32_t base_bytes;       // byte offset of this LOD's density ring inside the buffer resource (rbase, rbytes) below
     int32_t  addw[3];          // wrap0 - off: ring slot = wrap(ic + addw)
     uint32_t rx4;              // row pitch of the density ring in bytes (ring[0] * element size)
     float    ss[3];            // size * scale (the fused per-axis factor of the fast paths when scale = 2^-k)
     int32_t  slab;             // brick slab length in iterations (0: this LOD never stages bricks)
     // empty-space skipping: the 2x2x2-block maxima of this LOD's macro cells inside MarchParams::cells_all
+    // the buffer resource this LOD's texels are fetched through: the one allocation of all LODs' rings while it is
+    // below 4 GiB (one resource serves every lane of a mixed-LOD gather), else this LOD's ring alone
+    const void* rbase;
+    uint32_t rbytes;
     uint32_t cell_base;        // byte offset of the LOD's cell grid
     uint32_t cdim[3];          // cells per axis
     int32_t  cshift;           // log2 of the cell size (3 or 2)
@@ -73,7 +77,9 @@ struct MarchParams {
     const void* cells_all;         // dilated macro-cell maxima of all LODs (null: no skipping)
     uint32_t cells_all_bytes;
     const void* density_all;
-    uint32_t density_all_bytes;    // 0: allocation >= 4 GiB, buffer addressing unavailable
+    uint32_t density_all_bytes;    // size of that allocation when it is below 4 GiB (per_lod_rsrc = 0)
+    int32_t  span_ok;              // 0: some ring is beyond the span kernel's 32-bit / 24-bit addressing: straightforward kernel
+    int32_t  per_lod_rsrc;         // 1: the rings together are 4 GiB or more: one buffer resource per LOD
     int32_t  density_esh;          // log2 of the density element size: 0 u8, 1 u16, 2 f32 (svr_lod_desc::density_storage)
     // block -> tile mapping
     int32_t tiles_x, tiles_y;

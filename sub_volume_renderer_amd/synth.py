@@ -151,8 +151,24 @@ class LazyLod:
     """A numpy-like view of one LOD that generates blocks on demand (config C4:
     a 4096^3 volume is never resident).  ``labels=True`` selects the label array."""
 
+    # threads of the host generator per read: half of what the process may use, so that a streaming worker calling
+    # this beside a render loop does not exhaust the process's CPU quota (a throttled render thread stalls frames)
+    threads = 0
+
     def __init__(self, n: int, lod: int, labels: bool, n_labels: int = 4096):
         self.n, self.lod, self.labels, self.n_labels = n, lod, labels, n_labels
+        if not LazyLod.threads:
+            import os
+
+            cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:
+                with open("/sys/fs/cgroup/cpu.max") as f:
+                    q, per = f.read().split()[:2]
+                if q != "max":
+                    cpus = min(cpus, max(1, int(q) // int(per)))
+            except (OSError, ValueError):
+                pass
+            LazyLod.threads = max(1, min(8, cpus // 2))
         m = n >> lod
         self.shape = (m, m, m)
         self.ndim = 3
@@ -165,7 +181,8 @@ class LazyLod:
         shape = [(s.stop if s.stop is not None else dim) - o for s, o, dim in zip(slices, off, self.shape)]
         t = time.perf_counter()
         if host_lib() is not None:
-            d, l = block_host(self.n, self.lod, off, shape, self.n_labels, want=(not self.labels, self.labels))
+            d, l = block_host(self.n, self.lod, off, shape, self.n_labels, nthreads=LazyLod.threads,
+                              want=(not self.labels, self.labels))
         else:
             d, l = block(self.n, self.lod, off, shape, self.n_labels)
         out = l if self.labels else d

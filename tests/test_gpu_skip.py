@@ -20,14 +20,15 @@ def _sparse_pairs(n, seed, value=200, count=40, dtype=np.uint8):
     d0 = rng.integers(0, 12, (n, n, n)).astype(dtype)
     l0 = np.zeros((n, n, n), np.uint32)
     for k in range(count):
-        p = rng.integers(0, n, 3)
+        p = rng.integers(1, n - 2, 3)
         if k % 2 == 0:
-            p = (p // 8) * 8 + rng.choice([0, 7], 3)          # cell corners
+            p = (p // 8) * 8 + rng.choice([-1, 7], 3)         # 2^3 blobs straddling a cell corner (8 cells)
         elif k % 3 == 0:
-            p[k % 3] = (p[k % 3] // 8) * 8                     # cell faces
-        p = np.minimum(p, n - 1)
-        d0[tuple(p)] = value
-        l0[tuple(p)] = 1 + k
+            p[k % 3] = (p[k % 3] // 8) * 8 - 1                 # ... or a cell face
+        p = np.clip(p, 0, n - 2)
+        sl = tuple(slice(int(v), int(v) + 2) for v in p)
+        d0[sl] = value
+        l0[sl] = 1 + k
     pairs = [(d0, l0)]
     d, l = d0, l0
     for _ in range(2):
@@ -53,16 +54,16 @@ def _scene(n, pairs, threshold, cam, storage="native", w=192, h=128):
 
 
 @pytest.mark.parametrize("cam", ["K1", "K2", "-x", "+y", "-z", "diag"])
-@pytest.mark.parametrize("threshold", [200.0, 199.5, 200.5, 13.0])
+@pytest.mark.parametrize("threshold", [200.0, 199.5, 200.5, 5.0])
 def test_sparse_bright_voxels_on_cell_borders(cam, threshold):
     """threshold == the bright value (>= must hit), just below, just above (nothing reaches it: all rays run to
-    their end through skipped space), and just above the background noise (cells are all 'occupied')."""
+    their end through skipped space), and inside the background noise (every cell is 'occupied')."""
     spec = _scene(128, _sparse_pairs(128, 1), threshold, cam)
     scene = testing.build(spec)
     res, ref, rep = check(scene, want_hits=False)
     if threshold > 200.0 and threshold < 255.0:
         assert rep["n_hit"] == 0 and rep["n_miss"] > 1000       # nothing reaches it (single bright voxels may also be
-    elif threshold == 13.0:                                     # stepped over at 0.8 voxels per sample: no hit is owed)
+    elif threshold == 5.0:                                      # stepped over at 0.8 voxels per sample: no hit is owed)
         assert rep["n_hit"] > 1000
 
 
@@ -90,7 +91,7 @@ def test_skip_on_equals_skip_off_and_really_skips(storage, dtype, scale):
         assert torch.equal(getattr(off, k), v), k
     N.check(N.lib().svr_debug_counters(vol._rings.handle, census, 1), "svr_debug_counters")
     assert skipped > 1000 and census[7] == 0                # the default took skips, the A/B run none
-    check(scene)                                            # and both are the oracle's frame
+    check(scene, want_hits=False)                           # and both are the oracle's frame
 
 
 def test_stale_maxima_after_window_moves_stay_conservative():

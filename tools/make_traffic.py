@@ -18,7 +18,7 @@ prof, out = sys.argv[1], sys.argv[2]
 command = " ".join(sys.argv[3:])
 
 
-def mean_counter(name, pat="march_span"):
+def mean_counter(name, pat="8, false,"):        # the production build of march_span (not the instrumented <..., true, ...> one)
     vals = []
     for f in glob.glob(os.path.join(prof, "*", "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:

@@ -20,12 +20,13 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         if pat in r["Name"]:
             print(f"kernel-trace: {r['Name'][:90]}  calls={r['Calls']} avg={float(r['AverageNs'])/1e6:.4f} ms "
                   f"min={float(r['MinNs'])/1e6:.4f} max={float(r['MaxNs'])/1e6:.4f}")
+seen = set()
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in rows(f):
-        if pat in r["Kernel_Name"]:
-            print(f"dispatch: grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} vgpr={r['VGPR_Count']} "
+        if pat in r["Kernel_Name"] and r["Kernel_Name"] not in seen:      # one line per distinct kernel
+            seen.add(r["Kernel_Name"])
+            print(f"dispatch: {r['Kernel_Name'][:70]} grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} vgpr={r['VGPR_Count']} "
                   f"agpr={r.get('Accum_VGPR_Count')} sgpr={r['SGPR_Count']} lds={r['LDS_Block_Size']} scratch={r['Scratch_Size']}")
-            break
 acc = defaultdict(list)
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in rows(f):

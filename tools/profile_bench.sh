@@ -17,10 +17,26 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TC
   name=$(echo $pass | cut -d' ' -f1)
   timeout -k 10 300 rocprofv3 --pmc $pass --kernel-include-regex march --output-format csv -d $OUT/pmc_$name -- $CMD > $OUT/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/pmc_$name.log; exit 1; }
 done
+# the LMIP mode (early-out + empty-space skipping) on its own: every march dispatch of this trace is an LMIP frame
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lmip -- python3 $ROOT/tools/prof_driver.py lmip 1024 12 0 K1 > $OUT/trace_lmip.log 2>&1 || echo "lmip trace pass failed"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_SQ -- python3 $ROOT/tools/prof_driver.py lmip 1024 5 0 K1 > $OUT/lmip_pmc_SQ.log 2>&1 || echo "lmip pmc pass failed"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_FETCH -- python3 $ROOT/tools/prof_driver.py lmip 1024 5 0 K1 > $OUT/lmip_pmc_FETCH.log 2>&1 || echo "lmip fetch pass failed"
 grep -h '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
 python3 $ROOT/tools/pmc_summary.py $OUT march_span > $OUT/summary.txt 2>&1
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); head -1 $f > $OUT/kernel_stats_march.csv; grep march_ $f >> $OUT/kernel_stats_march.csv
 cp $f $OUT/kernel_stats_all.csv
 mkdir -p $ROOT/gpurun_out/profiles_$ROUND
 python3 $ROOT/tools/make_traffic.py $OUT $ROOT/gpurun_out/profiles_$ROUND/traffic.json "bench.py $ARGS" >> $OUT/summary.txt 2>&1
+f2=$(find $OUT/trace_lmip -name "*kernel_stats.csv" | head -1); [ -n "$f2" ] && { echo "--- LMIP mode (tools/prof_driver.py lmip 1024 12 0 K1)" >> $OUT/summary.txt; head -1 $f2 > $OUT/kernel_stats_march_lmip.csv; grep march_ $f2 >> $OUT/kernel_stats_march_lmip.csv; cat $OUT/kernel_stats_march_lmip.csv >> $OUT/summary.txt; }
+python3 - >> $OUT/summary.txt 2>&1 <<PY
+import csv, glob
+for d in ("lmip_pmc_SQ", "lmip_pmc_FETCH"):
+    acc = {}
+    for f in glob.glob("$OUT/" + d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "march_span" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print("  LMIP %-28s %16.1f  (mean of %d dispatches)" % (k, sum(v) / len(v), len(v)))
+PY
 cat $OUT/summary.txt
