@@ -880,7 +880,6 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             int held = 0;                                    // batches of this run held back behind a vetoed test
             do {
             run += held; held = 0;
-#ifndef SVR_EXP_NO_SKIP
             if (P.cells_all_bytes != 0u) {
                 const kparams_t Ps = fresh_params(P);
                 const int sb = Ps->lod[first].skip_batches;
@@ -947,7 +946,6 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     }
                 }
             }
-#endif
 
             // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a
             // slab (ic is monotone per axis: first and last sample bound the rest) is staged into LDS
