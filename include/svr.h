@@ -27,7 +27,7 @@ extern "C" {
 
 #define SVR_MAX_LODS 8
 #define SVR_MAX_CLIP_PLANES 8
-#define SVR_ABI_VERSION 4
+#define SVR_ABI_VERSION 5
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -50,11 +50,15 @@ typedef enum svr_dtype {
  * extent ring_dims (shader order), zero-initialised. */
 typedef struct svr_lod_desc {
     int32_t ring_dims[3];          /* (x, y, z) voxels = reversed shape_in_pixels */
-    int32_t density_storage;       /* SVR_F32: the reference's r32float texture.  SVR_U8: store the
-                                      density ring as bytes — allowed only when every upload's
-                                      source dtype is uint8, so that texel values (0..255, exact in
-                                      f32) and therefore all results are identical; 4x less HBM / L2 /
+    int32_t density_storage;       /* SVR_F32: the reference's r32float texture.  SVR_U8 / SVR_U16: store
+                                      the density ring in the sources' own integer type — allowed only when
+                                      every upload's source has that dtype, so that texel values (exact in
+                                      f32) and therefore all results are identical; 4x / 2x less HBM / L2 /
                                       LDS per voxel.  All LODs of a context use the same storage. */
+    int32_t no_labels;             /* 1: the volume has no segmentation (FUTURE.md:178-193 "make this optional"): no label
+                                      ring is allocated (4 of the 5 bytes per slot), uploads must pass labels = NULL,
+                                      every hit gets label 0 (-> colors[0], like unlabelled voxels: FUTURE.md:170-176).
+                                      All LODs of a context alike. */
 } svr_lod_desc;
 
 /* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.

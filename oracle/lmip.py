@@ -168,10 +168,23 @@ def render(rings, matrices, volume_dimensions_shader, material, width, height, r
     return out
 
 
+class _Zeros:
+    """An all-zero uint32 array of a given shape that materialises only the blocks asked of it."""
+
+    def __init__(self, shape):
+        self.shape, self.ndim, self.dtype = tuple(shape), len(shape), np.dtype(np.uint32)
+
+    def __getitem__(self, sl):
+        return np.zeros([s.stop - s.start for s in sl], np.uint32)
+
+
 def oracle_volume(spec) -> ring_oracle.OracleSubVolume:
     """Replay the spec's ``center_on_position`` calls on the CPU restatement."""
     mats = spec.matrices()
-    vol = ring_oracle.OracleSubVolume(list(spec.pairs), list(spec.ring_shapes), list(spec.chunk_shapes),
+    # a volume without segmentation (FUTURE.md:178-193) is a volume whose every label is 0 (the reference's
+    # "unlabelled data has segmentation id 0", FUTURE.md:170-176)
+    pairs = [(d, _Zeros(d.shape) if l is None else l) for d, l in spec.pairs]
+    vol = ring_oracle.OracleSubVolume(pairs, list(spec.ring_shapes), list(spec.chunk_shapes),
                                       world_inverse_matrix=np.linalg.inv(spec.world().matrix))
     del mats
     for position, sizes in spec.centers:

@@ -36,7 +36,7 @@ def dtype_code(dt) -> int:
 
 
 class LodDesc(C.Structure):
-    _fields_ = [("ring_dims", C.c_int32 * 3), ("density_storage", C.c_int32)]
+    _fields_ = [("ring_dims", C.c_int32 * 3), ("density_storage", C.c_int32), ("no_labels", C.c_int32)]
 
 
 SVR_U8, SVR_U16, SVR_F32 = 0, 1, 8

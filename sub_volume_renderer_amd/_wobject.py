@@ -104,6 +104,11 @@ class SubVolume(_HasWorld):
             if len(chunk) != density.ndim:
                 raise ValueError(f"chunk_shape_in_pixels[{level}] length must match data dimensions")
         data_segmentation_pairs, num_scales, base_data = pairs, levels, finest
+        # segmentations are optional here (the reference wishes for it, FUTURE.md:178-193): either every scale has
+        # one or none has; without them no label ring exists and every hit is coloured with colors[0]
+        unlabelled = [seg is None for _, seg in pairs]
+        if any(unlabelled) and not all(unlabelled):
+            raise ValueError("either every scale has a segmentation array or none has")
         if num_scales > N.SVR_MAX_LODS:
             raise ValueError(f"at most {N.SVR_MAX_LODS} scales are supported")
 
@@ -115,6 +120,7 @@ class SubVolume(_HasWorld):
             # "native": byte rings when every density source is uint8 (identical results, 4x less
             # memory traffic); "float32": always the reference's r32float layout
             density_storage=native_density_storage([d for d, _ in data_segmentation_pairs], ring_storage),
+            labels=not all(unlabelled),
         )
         self.wrapping_buffers: list[WrappingBuffer] = []
         for i, (scale_data, scale_segmentations) in enumerate(data_segmentation_pairs):

@@ -33,7 +33,7 @@ from ._geometry import Coordinate, Roi
 class DeviceRings:
     """The ``svr_ctx`` that owns the ring textures of all LODs of one volume."""
 
-    def __init__(self, ring_shapes, device: int | None = None, density_storage: str = "float32"):
+    def __init__(self, ring_shapes, device: int | None = None, density_storage: str = "float32", labels: bool = True):
         # ring_shapes: numpy-order voxel extents, one per LOD
         self.ring_shapes = [tuple(int(v) for v in s) for s in ring_shapes]
         self.device = device
@@ -42,6 +42,7 @@ class DeviceRings:
         if density_storage not in ("float32", "uint8", "uint16"):
             raise ValueError("density_storage must be 'float32', 'uint8' or 'uint16'")
         self.density_storage = density_storage
+        self.labels = bool(labels)            # False: a volume without segmentation, no label rings at all
         self._handle = None
 
     @property
@@ -52,6 +53,7 @@ class DeviceRings:
             for d, s in zip(descs, self.ring_shapes):
                 d.ring_dims[:] = s[::-1]
                 d.density_storage = {"uint8": N.SVR_U8, "uint16": N.SVR_U16}.get(self.density_storage, N.SVR_F32)
+                d.no_labels = 0 if self.labels else 1
             device = self.device
             if device is None:
                 import torch
@@ -191,7 +193,8 @@ class WrappingBuffer:
     def rings(self) -> DeviceRings:
         if self._rings is None:
             self._rings = DeviceRings([tuple(self.shape_in_pixels)],
-                                      density_storage=native_density_storage([self.backing_data], self._ring_storage))
+                                      density_storage=native_density_storage([self.backing_data], self._ring_storage),
+                                      labels=self.segmentations is not None)
             self._lod = 0
         return self._rings
 
@@ -389,15 +392,17 @@ class WrappingBuffer:
         if hasattr(self.backing_data, "origin") and hasattr(self.backing_data, "read"):
             read_roi = src + Coordinate(self.backing_data.origin)  # tensorstore (:307-310)
         density = _materialise(self.backing_data[read_roi.to_slices()])
-        labels = _materialise(self.segmentations[read_roi.to_slices()])
+        # a volume without segmentation (FUTURE.md:178-193): nothing to read, no label ring to write
+        labels = None if self.segmentations is None else _materialise(self.segmentations[read_roi.to_slices()])
         self._upload(dst, density, labels)
 
     def _upload(self, dst_px: Roi, density, labels):
         lib = N.lib()
         off = N.i3(dst_px.offset[::-1])
         shp = N.i3(dst_px.shape[::-1])
-        if _is_device_tensor(density) != _is_device_tensor(labels):
+        if labels is not None and _is_device_tensor(density) != _is_device_tensor(labels):
             raise TypeError("density and segmentation sources must both be host or both be device arrays")
+        null = (None, 0, N.l3((0, 0, 0)))
         if _is_device_tensor(density):
             import torch
 
@@ -405,6 +410,9 @@ class WrappingBuffer:
             torch.cuda.current_stream(density.device).synchronize()
             args = []
             for t in (density, labels):
+                if t is None:
+                    args += list(null)
+                    continue
                 dt = np.dtype(str(t.dtype).replace("torch.", ""))
                 es = t.element_size()
                 args += [C.c_void_p(t.data_ptr()), N.dtype_code(dt), N.l3([s * es for s in t.stride()][::-1])]
@@ -412,14 +420,18 @@ class WrappingBuffer:
                     "svr_upload_region_device")
             return
         density = np.asarray(density)
-        labels = np.asarray(labels)
-        if tuple(density.shape) != tuple(dst_px.shape) or tuple(labels.shape) != tuple(dst_px.shape):
-            raise ValueError(f"source block shape {density.shape}/{labels.shape} != destination {dst_px.shape}")
+        if tuple(density.shape) != tuple(dst_px.shape):
+            raise ValueError(f"source block shape {density.shape} != destination {dst_px.shape}")
+        largs = list(null)
+        if labels is not None:
+            labels = np.asarray(labels)
+            if tuple(labels.shape) != tuple(dst_px.shape):
+                raise ValueError(f"segmentation block shape {labels.shape} != destination {dst_px.shape}")
+            largs = [C.c_void_p(labels.ctypes.data), N.dtype_code(labels.dtype), N.l3(labels.strides[::-1])]
         N.check(
             lib.svr_upload_region(
                 self.rings.handle, self._lod, off, shp,
-                C.c_void_p(density.ctypes.data), N.dtype_code(density.dtype), N.l3(density.strides[::-1]),
-                C.c_void_p(labels.ctypes.data), N.dtype_code(labels.dtype), N.l3(labels.strides[::-1]),
+                C.c_void_p(density.ctypes.data), N.dtype_code(density.dtype), N.l3(density.strides[::-1]), *largs,
             ),
             "svr_upload_region",
         )

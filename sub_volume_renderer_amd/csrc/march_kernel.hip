@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t sample_label(const MarchParams& P, float cx,
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         size_t idx;
-        if (lod_texel(P.lod[l], dx, dy, dz, idx)) return P.lod[l].labels[idx];
+        if (lod_texel(P.lod[l], dx, dy, dz, idx)) return P.lod[l].labels ? P.lod[l].labels[idx] : 0u;   // no label rings: 0
     }
     return 0u;
 }
@@ -945,6 +945,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         if (run > cap) { held = run - cap; run = cap; }
                     }
                 }
+                lap(10);
             }
 
             // ---- LDS brick slabs (u8 rings).  The exact bounding box of the wave's samples over a

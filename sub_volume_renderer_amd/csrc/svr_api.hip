@@ -54,6 +54,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
                     "svr_create: density_storage must be SVR_F32, SVR_U8 or SVR_U16");
         SVR_REQUIRE(lods[l].density_storage == lods[0].density_storage,
                     "svr_create: all LODs must use the same density_storage");
+        SVR_REQUIRE((lods[l].no_labels != 0) == (lods[0].no_labels != 0), "svr_create: all LODs must agree on no_labels");
     }
     DeviceGuard guard(device);
     svr_ctx* c = new svr_ctx();
@@ -70,6 +71,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
     c->cells_raw_all = c->cells_dil_all = nullptr; c->cells_all_bytes = 0;
     c->density_storage = lods[0].density_storage;
+    c->no_labels = lods[0].no_labels != 0 ? 1 : 0;
     c->density_u8 = lods[0].density_storage == SVR_U8 ? 1 : 0;
     c->staged_bytes = 0; c->upload_seconds = 0.0;
 
@@ -96,18 +98,18 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->density_all_bytes = total * des + 64;                 // + slack: 16-byte brick loads may overrun a row end
     // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
     if (hipMalloc((void**)&c->density_all, c->density_all_bytes) != hipSuccess ||
-        hipMalloc((void**)&c->labels_all, total * sizeof(uint32_t)) != hipSuccess) {
+        (!c->no_labels && hipMalloc((void**)&c->labels_all, total * sizeof(uint32_t)) != hipSuccess)) {
         svr_set_error("svr_create: out of device memory for ring textures");
         return fail(SVR_ERR_NOMEM);
     }
     if (hipMemsetAsync(c->density_all, 0, c->density_all_bytes, c->upload_stream) != hipSuccess ||
-        hipMemsetAsync(c->labels_all, 0, total * sizeof(uint32_t), c->upload_stream) != hipSuccess) {
+        (!c->no_labels && hipMemsetAsync(c->labels_all, 0, total * sizeof(uint32_t), c->upload_stream) != hipSuccess)) {
         svr_set_error("svr_create: memset failed");
         return fail(SVR_ERR_HIP);
     }
     for (int l = 0; l < num_lods; ++l) {
         c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
-        c->lod[l].labels = c->labels_all + c->lod_base_bytes[l];
+        c->lod[l].labels = c->no_labels ? nullptr : c->labels_all + c->lod_base_bytes[l];
     }
     {   // macro-cell maxima (empty-space skipping): one grid of cells per LOD whose extents are multiples of 8.
         // The finest level gets 8^3-slot cells, the coarser ones 4^3: their structures are half / a quarter the size
@@ -370,6 +372,7 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     SVR_REQUIRE(!density || (des && density_strides), "svr_upload_region: bad density dtype/strides");
     SVR_REQUIRE(!labels || (les && labels_strides), "svr_upload_region: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
+    SVR_REQUIRE(!labels || !c->no_labels, "svr_upload_region: the context was created without label rings (no_labels)");
     SVR_REQUIRE(!density || storage_accepts(c->density_storage, density_dtype),
                 "svr_upload_region: the context's integer density storage only accepts sources of that same dtype");
     if (shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return SVR_OK;
@@ -441,6 +444,7 @@ int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], cons
     SVR_REQUIRE(!density || (svr_dtype_size(density_dtype) && density_strides), "svr_upload_region_device: bad density dtype/strides");
     SVR_REQUIRE(!labels || (svr_dtype_size(labels_dtype) && labels_strides), "svr_upload_region_device: bad labels dtype/strides");
     if (!density && !labels) return SVR_OK;
+    SVR_REQUIRE(!labels || !c->no_labels, "svr_upload_region_device: the context was created without label rings (no_labels)");
     SVR_REQUIRE(!density || storage_accepts(c->density_storage, density_dtype),
                 "svr_upload_region_device: the context's integer density storage only accepts sources of that same dtype");
     DeviceGuard guard(c->device);
@@ -532,7 +536,7 @@ int svr_clear_lod(svr_ctx* c, int lod) {
     LodStorage& L = c->lod[lod];
     std::lock_guard<std::mutex> upload_lock(c->upload_mu);
     SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * svr_dtype_size(c->density_storage), c->upload_stream));
-    SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
+    if (L.labels) SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
     if (L.cells_raw) {
         const size_t cb = (size_t)L.cdim[0] * L.cdim[1] * L.cdim[2] * svr_dtype_size(c->density_storage);
         SVR_HIP_TRY(hipMemsetAsync(L.cells_raw, 0, cb, c->upload_stream));
@@ -550,6 +554,11 @@ int svr_read_region(svr_ctx* c, int lod, const int32_t off[3], const int32_t sha
     DeviceGuard guard(c->device);
     LodStorage& L = c->lod[lod];
     float* dtmp = nullptr; uint32_t* ltmp = nullptr;
+    if (labels_out && !L.labels) {                     // no label rings: every label reads as 0
+        memset(labels_out, 0, n * sizeof(uint32_t));
+        labels_out = nullptr;
+        if (!density_out) return SVR_OK;
+    }
     SVR_HIP_TRY(hipStreamSynchronize(c->upload_stream));
     if (density_out) SVR_HIP_TRY(hipMalloc((void**)&dtmp, n * sizeof(float)));
     if (labels_out && hipMalloc((void**)&ltmp, n * sizeof(uint32_t)) != hipSuccess) {

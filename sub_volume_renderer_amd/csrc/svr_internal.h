@@ -129,6 +129,7 @@ struct svr_ctx {
     void*     density_all;           // one allocation, LOD rings at 256-byte aligned offsets
     int       density_storage;       // ring element type: SVR_F32 (reference layout), SVR_U8 or SVR_U16
     int       density_u8;            // density_storage == SVR_U8
+    int       no_labels;             // the volume has no segmentation: no label rings
     uint64_t  staged_bytes;          // bytes sent through the pinned staging slots so far (diagnostics)
     double    upload_seconds;        // host wall-clock time spent inside svr_upload_region
     uint32_t* labels_all;

@@ -158,3 +158,13 @@ def test_world_transform_and_camera_matrices():
     t = svr.AffineTransform()
     t.position = (1, 2, 3); t.scale_z = 6
     assert np.allclose(t.inverse_matrix @ t.matrix, np.eye(4)) and t.matrix[2, 2] == 6
+
+
+def test_segmentations_are_optional_but_all_or_none():
+    """FUTURE.md:178-193: label-less volumes; mixing labelled and unlabelled scales is refused."""
+    d0, d1 = np.zeros((16, 16, 16), np.uint8), np.zeros((8, 8, 8), np.uint8)
+    vol = SubVolume(SubVolumeMaterial(0.5), [(d0, None), (d1, None)], (2, 2, 2), (4, 4, 4))
+    assert vol._rings.labels is False and vol.wrapping_buffers[0].segmentations is None
+    assert SubVolume(SubVolumeMaterial(0.5), [(d0, d0), (d1, d1)], (2, 2, 2), (4, 4, 4))._rings.labels is True
+    with pytest.raises(ValueError):
+        SubVolume(SubVolumeMaterial(0.5), [(d0, d0), (d1, None)], (2, 2, 2), (4, 4, 4))

@@ -94,3 +94,45 @@ def test_uint16_threshold_edges():
         spec.material.update(lmip_threshold=thr, clim=(0.0, 65535.0))
         spec.centers = [((7.5, 7.5, 7.5), [(16, 16, 16)])]
         check(testing.build(spec), want_hits=False)
+
+
+@pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
+def test_volume_without_segmentation_renders_every_hit_with_label_zero(inside):
+    """FUTURE.md:178-193 ("make this optional"): pairs of (density, None) — no label rings are allocated, every hit
+    carries label 0 and the hue of colors[0], the density side is untouched."""
+    import ctypes as C
+
+    import torch
+
+    from sub_volume_renderer_amd import _native as N
+
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside)
+    labelled = lmip.render_spec(spec)
+    spec.pairs = [(d, None) for d, _ in spec.pairs]
+    scene = testing.build(spec)
+    res, ref, rep = check(scene)
+    assert int(res.label.abs().sum()) == 0 and rep["n_hit"] > 100
+    np.testing.assert_array_equal(ref.flags, labelled.flags)          # same hits, same steps: only the hue changes
+    np.testing.assert_array_equal(ref.steps, labelled.steps)
+    np.testing.assert_array_equal(ref.depth, labelled.depth)
+    lab_ptr = C.c_void_p(1)
+    N.check(N.lib().svr_lod_device_ptrs(scene.volume._rings.handle, 0, None, C.byref(lab_ptr)), "ptrs")
+    assert not lab_ptr.value                                           # no label ring exists
+    b = scene.volume.wrapping_buffers[0]
+    assert int(b.segmentations_texture.data.sum()) == 0
+    # windows move, blocking and asynchronous, as for labelled volumes
+    orac = lmip.oracle_volume(spec)
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    for k in (1, 2):
+        p = eye + d * 9.0 * k
+        scene.volume.center_on_position(tuple(p), asynchronous=(k == 2))
+        scene.volume.poll_uploads(wait=True)
+        orac.center_on_position(tuple(p))
+    for bb, ob in zip(scene.volume.wrapping_buffers, orac.wrapping_buffers):
+        np.testing.assert_array_equal(bb.texture.data, ob.texture)
+    with pytest.raises(ValueError):                                    # a label source for a context without label rings
+        scene.volume.wrapping_buffers[0]._upload(__import__("sub_volume_renderer_amd").Roi((0, 0, 0), (8, 8, 16)),
+                                                 np.zeros((8, 8, 16), np.uint8), np.zeros((8, 8, 16), np.uint32))
+    torch.cuda.synchronize()

@@ -23,7 +23,7 @@ N.check(N.lib().svr_set_variant(vol._rings.handle, variant), "variant")
 for mode in ("full", "lmip"):
     vol.material.lmip_threshold = float("inf") if mode == "full" else 127.5
     for (x0, y0, w, h) in [(956, 536, 8, 8), (400, 300, 8, 8), (1500, 800, 8, 8), (928, 508, 64, 64), (704, 284, 512, 512),
-                           (0, 0, 1920, 8), (0, 536, 1920, 8), (0, 536, 1920, 64)]:
+                           (0, 0, 1920, 8), (0, 536, 1920, 8), (0, 536, 1920, 64), (0, 0, 1920, 1080)]:
         reg = FrameRegion.tile(x0, y0, w, h)
         tm = (C.c_uint64 * 16)(); dbg = (C.c_uint32 * 8)()
         N.lib().svr_debug_timers(vol._rings.handle, tm, 1); N.lib().svr_debug_counters(vol._rings.handle, dbg, 1)
@@ -31,7 +31,7 @@ for mode in ("full", "lmip"):
         torch.cuda.synchronize()
         N.lib().svr_debug_timers(vol._rings.handle, tm, 1); N.lib().svr_debug_counters(vol._rings.handle, dbg, 1)
         tot = max(1, sum(tm))
-        names = ["prol", "span", "gen", "slabdma", "wait", "brick", "direct", "epil", "slabred", "slabsalu", "t10", "t11", "t12", "t13", "t14", "t15"]
+        names = ["prol", "span", "gen", "slabdma", "wait", "brick", "direct", "epil", "slabred", "slabsalu", "skip", "t11", "t12", "t13", "t14", "t15"]
         tline = " ".join(f"{nm}={100*t/tot:.1f}%" for nm, t in zip(names, tm)) + f" | cycles/wave={tot/max(1,dbg[6]):.0f} census={list(dbg)[:7]}"
         steps = r.steps.to(torch.int64)
         r = vol.render(cam, W, H, region=reg)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the HIP march against the CPU oracle: random volumes (1-4 LODs, random chunk
-and ring shapes, anisotropic, u8 or f32 rings), ring windows, cameras (outside / inside / grazing), materials,
-frame sizes, frame regions and kernel variants.  Integer planes must be identical, float planes within 1e-4.
+and ring shapes, anisotropic, u8 / u16 / f32 rings, with or without segmentation), ring windows, cameras (outside /
+inside / grazing), materials (LMIP and MIP, clipping planes), frame sizes, frame regions and kernel variants
+(empty-space skipping on and off, bricks always / never / by probe, tile shapes, placements).  Integer planes must be identical, float planes within 1e-4.
 usage: fuzz_parity.py [cases] [first_seed] [brick]      (prints one line per failing case, then a summary)"""
 import os
 import sys
@@ -12,10 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import lmip  # noqa: E402
 from sub_volume_renderer_amd import FrameRegion, _native as N, testing  # noqa: E402
 
-VARIANTS = [0x000, 0x000, 0x200, 0x100, 0x002, 0x2000, 0x4000, 0x250, 0x230, 0x001, 0x204, 0xA202]
+VARIANTS = [0x000, 0x000, 0x200, 0x100, 0x002, 0x2000, 0x4000, 0x250, 0x230, 0x001, 0x204, 0xA202, 0x008, 0x208]
 
 
-BRICK_VARIANTS = [0x200, 0x200, 0x204, 0x230, 0x250, 0xA202, 0x2200, 0x000]
+BRICK_VARIANTS = [0x200, 0x200, 0x204, 0x230, 0x250, 0xA202, 0x2200, 0x000, 0x208]
 
 
 def random_spec(seed, brick=False):
@@ -93,6 +94,26 @@ def random_spec(seed, brick=False):
     if rng.random() < 0.2:
         spec.colorspace = "linear"
     spec.ring_storage = "native" if (brick or rng.random() < 0.8) else "float32"
+    # round-2 features (drawn after everything else, so that earlier seeds keep their geometry)
+    extra = rng.random(5)
+    if extra[0] < 0.15 and not f32data:                   # uint16 sources -> uint16 rings
+        spec.pairs = [(d.astype(np.uint16) * 257, l) for d, l in spec.pairs]
+        m = spec.material
+        m["lmip_threshold"] = m["lmip_threshold"] * 257.0
+        m["clim"] = (m["clim"][0] * 257.0, m["clim"][1] * 257.0)
+    if extra[1] < 0.12:
+        spec.material["render_mode"] = "mip"
+    if extra[2] < 0.15:                                   # 1-3 world-space planes through points of the volume
+        planes = []
+        for _ in range(int(rng.integers(1, 4))):
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            pt = (size_xyz * rng.uniform(0.1, 0.9, 3)) * np.array(spec.world_scale) + np.array(spec.world_position)
+            planes.append((float(nrm[0]), float(nrm[1]), float(nrm[2]), float(nrm @ pt)))
+        spec.material["clipping_planes"] = planes
+        spec.material["clipping_mode"] = "ALL" if extra[3] < 0.3 else "ANY"
+    if extra[4] < 0.08:                                   # a volume without segmentation
+        spec.pairs = [(d, None) for d, _ in spec.pairs]
     region = None
     r = rng.random()
     if r < 0.2:
