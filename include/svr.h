@@ -232,7 +232,9 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
  * bits 11-12 timing experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
- * bits 13-15 block -> tile placement: 0 = 64x64-pixel chunks of tiles dealt round-robin to the XCDs (default),
+ * bits 13-15 block -> tile placement: 0 = 64x64-pixel chunks of tiles sorted by the length of their rays for the draw's
+ *            camera, longest first, dealt to the XCDs in snake order (default; SVR_STATIC_PLACEMENT=1 in the environment:
+ *            the same chunks in raster order, round-robin),
  *            1 = one contiguous run of tiles per XCD, 2.. = single tiles, 64x32, 32x32, 128x64, 32x16, 128x128 chunks
  * bits 16-23 probe threshold in L1 lookups per wave-load (0 = default 32)
  * bits 24-31 mask of LODs allowed to stage bricks (0 = default: all) */

@@ -171,6 +171,11 @@ int svr_destroy(svr_ctx* c) {
     for (float* p : c->colors_retired) (void)hipFree(p);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto& t : c->tile_orders) if (t.dev) (void)hipFree(t.dev);
+    for (auto& t : c->cost_orders) {
+        if (t.dev) (void)hipFree(t.dev);
+        if (t.host) (void)hipHostFree(t.host);
+        if (t.copied) (void)hipEventDestroy(t.copied);
+    }
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
     for (auto& m : c->render_marks) if (m.done) (void)hipEventDestroy(m.done);
     for (auto& t : c->tickets) if (t) (void)hipEventDestroy(t);
@@ -609,6 +614,67 @@ static void build_tile_order(int tx, int ty, int cw, int ch, std::vector<uint32_
         for (size_t j = 0; j < lists[k].size(); ++j) order[8 * j + (size_t)k] = lists[k][j];
 }
 
+// Length (in finest-level voxels) of the part of the pixel's ray inside the proxy box: what a full march of that
+// pixel costs, up to the constant step.  Same geometry as setup_ray, evaluated loosely (placement only).
+static float ray_cost(const MarchParams& P, float px_frame, float py_frame) {
+    const float ndcx = 2.0f * px_frame / (float)P.frame.frame_w - 1.0f, ndcy = 1.0f - 2.0f * py_frame / (float)P.frame.frame_h;
+    const float nv[4] = { ndcx, ndcy, -1.0f, 1.0f }, fv[4] = { ndcx, ndcy, 1.0f, 1.0f };
+    float n4[4], f4[4];
+    mat_vec4(P.ndc_to_data, nv, n4);
+    mat_vec4(P.ndc_to_data, fv, f4);
+    float o[3], d[3], len = 0.0f;
+    for (int a = 0; a < 3; ++a) { o[a] = n4[a] / n4[3]; d[a] = f4[a] / f4[3] - o[a]; len += d[a] * d[a]; }
+    len = sqrtf(len);
+    if (!(len > 0.0f)) return 0.0f;
+    float t0 = 0.0f, t1 = len;
+    for (int a = 0; a < 3; ++a) {
+        const float r = d[a] / len, lo = -0.5f, hi = P.size[a] - 0.5f;
+        if (fabsf(r) < 1e-12f) { if (o[a] < lo || o[a] > hi) return 0.0f; continue; }
+        const float ta = (lo - o[a]) / r, tb = (hi - o[a]) / r;
+        t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+    }
+    return t1 > t0 ? t1 - t0 : 0.0f;
+}
+
+// Cost-sorted placement: chunks of tiles ordered by the length of their rays, longest first, and dealt to the XCDs
+// in snake order (0..7, 7..0, ...): every XCD gets the same share of the work, the expensive tiles start first and
+// the cheap ones fill the end of the frame (longest-processing-time-first scheduling of the frame's tail).
+static void build_tile_order_by_cost(const MarchParams& P, int tx, int ty, int tile_w, int tile_h, int cw, int ch,
+                                     std::vector<uint32_t>& order) {
+    struct Chunk { float cost; int cx, cy; };
+    std::vector<Chunk> chunks;
+    for (int cy = 0; cy < ty; cy += ch)
+        for (int cx = 0; cx < tx; cx += cw) {
+            // output pixel of the chunk's centre -> frame pixel (svr_frame mapping)
+            const int ox = std::min(P.frame.out_w - 1, (cx + cw / 2) * tile_w + tile_w / 2);
+            const int oy = std::min(P.frame.out_h - 1, (cy + ch / 2) * tile_h + tile_h / 2);
+            const float fx = (float)(P.frame.x0 + ox) + 0.5f;
+            const float fy = (float)(P.frame.y0 + (oy / P.frame.band_h) * P.frame.band_pitch + oy % P.frame.band_h) + 0.5f;
+            chunks.push_back({ ray_cost(P, fx, fy), cx, cy });
+        }
+    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& a, const Chunk& b) { return a.cost > b.cost; });
+    const int n = tx * ty;
+    std::vector<uint32_t> lists[8];
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        const int round = (int)(i / 8), pos = (int)(i % 8), k = (round & 1) ? 7 - pos : pos;
+        for (int y = chunks[i].cy; y < std::min(chunks[i].cy + ch, ty); ++y)
+            for (int x = chunks[i].cx; x < std::min(chunks[i].cx + cw, tx); ++x) lists[k].push_back((uint32_t)(y * tx + x));
+    }
+    // XCD k runs blocks k, k + 8, ...: exactly ceil((n - k) / 8) of them; surplus tiles (the cheapest: list tails) move over
+    std::vector<uint32_t> spare;
+    for (int k = 0; k < 8; ++k) {
+        const size_t need = n > k ? (size_t)((n - k + 7) / 8) : 0;
+        while (lists[k].size() > need) { spare.push_back(lists[k].back()); lists[k].pop_back(); }
+    }
+    for (int k = 0; k < 8; ++k) {
+        const size_t need = n > k ? (size_t)((n - k + 7) / 8) : 0;
+        while (lists[k].size() < need) { lists[k].push_back(spare.back()); spare.pop_back(); }
+    }
+    order.assign((size_t)n, 0u);
+    for (int k = 0; k < 8; ++k)
+        for (size_t j = 0; j < lists[k].size(); ++j) order[8 * j + (size_t)k] = lists[k][j];
+}
+
 static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, int mode, const uint32_t** out) {
     *out = nullptr;
     if (mode == 1 || tx * ty <= 0) return SVR_OK;             // in-kernel contiguous mapping
@@ -634,6 +700,55 @@ static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, in
     return SVR_OK;
 }
 
+// The cost-sorted table of this draw: kept per stream, recomputed only when the camera / frame region changed.
+// The new table is written into the stream's pinned buffer and copied on that same stream, i.e. behind the
+// previous draw of that stream (which may still read the old table) and before this one.
+static int tile_order_by_cost_for(svr_ctx* c, const MarchParams& P, int tile_w, int tile_h, hipStream_t stream,
+                                  const uint32_t** out) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(P.ndc_to_data, sizeof(P.ndc_to_data)); mix(P.size, sizeof(P.size)); mix(&P.frame, sizeof(P.frame));
+    mix(&tile_w, sizeof(tile_w)); mix(&tile_h, sizeof(tile_h)); mix(&P.tiles_x, sizeof(P.tiles_x)); mix(&P.tiles_y, sizeof(P.tiles_y));
+    svr_ctx::CostOrder* slot = nullptr;
+    for (auto& t : c->cost_orders) if (t.stream == stream) { slot = &t; break; }
+    DeviceGuard guard(c->device);
+    if (!slot) {
+        if (c->cost_orders.size() >= 64) {                   // a caller cycling through many streams: recycle the oldest slot
+            svr_ctx::CostOrder old = c->cost_orders.front();
+            SVR_HIP_TRY(hipStreamSynchronize(old.stream));
+            c->cost_orders.erase(c->cost_orders.begin());
+            old.stream = stream; old.valid = false;
+            c->cost_orders.push_back(old);
+        } else {
+            svr_ctx::CostOrder t{ stream, nullptr, nullptr, 0, nullptr, 0, false };
+            SVR_HIP_TRY(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
+            c->cost_orders.push_back(t);
+        }
+        slot = &c->cost_orders.back();
+    }
+    const size_t n = (size_t)P.tiles_x * (size_t)P.tiles_y;
+    if (slot->valid && slot->key == h && slot->cap >= n) { *out = slot->dev; return SVR_OK; }
+    if (slot->cap < n) {
+        if (slot->dev) { SVR_HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(slot->dev); (void)hipHostFree(slot->host); slot->dev = slot->host = nullptr; slot->cap = 0; }
+        const size_t cap = n + n / 4 + 64;
+        if (hipMalloc((void**)&slot->dev, cap * sizeof(uint32_t)) != hipSuccess ||
+            hipHostMalloc((void**)&slot->host, cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            svr_set_error("svr_render: out of memory for the block -> tile table"); return SVR_ERR_NOMEM;
+        }
+        slot->cap = cap;
+    } else if (slot->valid) {
+        SVR_HIP_TRY(hipEventSynchronize(slot->copied));      // the pinned buffer's previous contents have left for the device
+    }
+    std::vector<uint32_t> order;
+    build_tile_order_by_cost(P, P.tiles_x, P.tiles_y, tile_w, tile_h, std::max(1, 64 / tile_w), std::max(1, 64 / tile_h), order);
+    memcpy(slot->host, order.data(), n * sizeof(uint32_t));
+    SVR_HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    SVR_HIP_TRY(hipEventRecord(slot->copied, stream));
+    slot->key = h; slot->valid = true;
+    *out = slot->dev;
+    return SVR_OK;
+}
+
 // Can the span kernel address this context's rings?  Every LOD's ring must stay below 4 GiB (32-bit byte offsets
 // into its buffer resource) and within the 24-bit row index and row pitch of the exact general path; otherwise
 // every render takes the straightforward kernel's 64-bit addressing.
@@ -646,7 +761,8 @@ static bool span_addressable(const svr_ctx* c) {
     return true;
 }
 
-static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, MarchParams& P) {
+static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, hipStream_t stream,
+                       MarchParams& P) {
     SVR_REQUIRE(c && cam && fr && out && out->rgba, "svr_render: null argument");
     SVR_REQUIRE(c->material_set, "svr_render: svr_set_material has not been called");
     SVR_REQUIRE(fr->frame_w > 0 && fr->frame_h > 0 && fr->out_w > 0 && fr->out_h > 0, "svr_render: empty frame");
@@ -722,6 +838,13 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)
         const int rc_order = tile_order_for(c, P.tiles_x, P.tiles_y, bw, bh, (c->variant >> 13) & 7, &P.tile_order);
         if (rc_order) return rc_order;
+        // default placement: the same 64x64-pixel chunks, but sorted by the length of their rays for THIS camera
+        // (longest first, snake-dealt to the XCDs); SVR_STATIC_PLACEMENT keeps the camera-independent table (A/B)
+        static const bool static_placement = getenv("SVR_STATIC_PLACEMENT") != nullptr;
+        if (!static_placement && ((c->variant >> 13) & 7) == 0 && P.tiles_x * P.tiles_y > 0) {
+            const int rc_lpt = tile_order_by_cost_for(c, P, bw, bh, stream, &P.tile_order);
+            if (rc_lpt) return rc_lpt;
+        }
     }
     for (int l = 0; l < c->num_lods; ++l) {
         const LodStorage& L = c->lod[l];
@@ -801,7 +924,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
 
 int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, void* stream) {
     MarchParams P;
-    int rc = fill_params(c, cam, fr, out, P);
+    int rc = fill_params(c, cam, fr, out, static_cast<hipStream_t>(stream), P);
     if (rc) return rc;
     DeviceGuard guard(c->device);
     // the caller's stream; NULL is the device's default stream (what torch.cuda.current_stream() is
@@ -816,7 +939,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
                     int iters, float* avg_ms) {
     SVR_REQUIRE(avg_ms && iters >= 1, "svr_time_render: bad arguments");
     MarchParams P;
-    int rc = fill_params(c, cam, fr, out, P);
+    int rc = fill_params(c, cam, fr, out, c->render_stream, P);
     if (rc) return rc;
     DeviceGuard guard(c->device);
     hipStream_t s = c->render_stream;

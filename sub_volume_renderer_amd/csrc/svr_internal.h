@@ -167,6 +167,10 @@ struct svr_ctx {
     // block -> tile tables (one per frame tiling and policy; entries are never rewritten)
     struct TileOrder { int tiles_x, tiles_y, mode; uint32_t* dev; };
     std::vector<TileOrder> tile_orders;
+    // cost-sorted block -> tile tables (default placement): one per stream that carries renders, rewritten (through
+    // pinned memory, on that stream) whenever the camera or the frame region changes
+    struct CostOrder { hipStream_t stream; uint32_t* dev; uint32_t* host; size_t cap; hipEvent_t copied; uint64_t key; bool valid; };
+    std::vector<CostOrder> cost_orders;
     hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
     std::atomic<bool> marker_set;
     // svr_upload_ticket / svr_ticket_pending: ticket t lives in tickets[t % kTickets]
