@@ -313,6 +313,11 @@ def main():
     def timed(loop, mode, nframes, warmup):
         """W untimed frames, then EXACTLY nframes bracketed by barrier + synchronize; max over ranks."""
         set_mode(mode == "full")
+        # block -> tile placement: with several frames in flight the next frame's head fills this frame's tail anyway,
+        # and the camera-independent table (policy 7) is ~1 % faster; one frame at a time wants the cost-sorted one
+        # (policy 0, the library's default).  An explicit --variant placement is left alone.
+        placement = (7 << 13) if (loop.F > 1 and not (args.variant >> 13) & 7) else 0
+        N.check(N.lib().svr_set_variant(handle, args.variant | placement), "svr_set_variant")
         for _ in range(warmup):
             loop.frame()
         loop.drain()
@@ -353,6 +358,7 @@ def main():
         # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
         def kernel_ms(mode, iters=10):
             set_mode(mode == "full")
+            N.check(N.lib().svr_set_variant(handle, args.variant), "svr_set_variant")
             vol.prepare()
             cb, fb = vol.camera_block(cam), vol.frame_block(W, H, region)
             ob = N.Outputs()
@@ -403,6 +409,9 @@ def main():
                                    f"{'rgba+depth+label' if want_all else 'rgba'} via {transport}",
                     "kernel_variant": args.variant,
                     "frames_in_flight": loop.F,
+                    "placement": "64x64-pixel chunks in raster order (svr_set_variant policy 7) for the pipelined loop; "
+                                 "cost-sorted per camera (policy 0, default) for `sequential` and `roofline`"
+                                 if (loop.F > 1 and not (args.variant >> 13) & 7) else "as --variant says (0: cost-sorted per camera)",
                     "ring_storage": vol._rings.density_storage,
                 },
                 # the same K-step region repeated, and with ONE frame at a time (no overlap of tails and heads):

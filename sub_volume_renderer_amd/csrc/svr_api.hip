@@ -679,7 +679,8 @@ static int tile_order_for(svr_ctx* c, int tx, int ty, int tile_w, int tile_h, in
     *out = nullptr;
     if (mode == 1 || tx * ty <= 0) return SVR_OK;             // in-kernel contiguous mapping
     // chunk size in pixels per policy
-    static const int kChunk[8][2] = { { 64, 64 }, { 0, 0 }, { 1, 1 }, { 64, 32 }, { 32, 32 }, { 128, 64 }, { 32, 16 }, { 128, 128 } };
+    // (policy 7: the camera-independent 64x64 table of round 1 — what policy 0 falls back to with SVR_STATIC_PLACEMENT)
+    static const int kChunk[8][2] = { { 64, 64 }, { 0, 0 }, { 1, 1 }, { 64, 32 }, { 32, 32 }, { 128, 64 }, { 32, 16 }, { 64, 64 } };
     const int cw = std::max(1, kChunk[mode][0] / tile_w), ch = std::max(1, kChunk[mode][1] / tile_h);
     const int key = mode | cw << 8 | ch << 16;
     for (const auto& t : c->tile_orders)

@@ -52,7 +52,7 @@ def test_synthetic_three_lods(inside, full, storage):
 
 @pytest.mark.parametrize("variant", [0x000, 0x200, 0x100, 0x001, 0x250, 0x230, 0x202, 0x2200, 0x4200, 0xE202],
                          ids=["auto", "brick", "nobrick", "simple", "brick16x4", "brick4x16", "brick-wg4",
-                              "brick-contiguous", "brick-tilewise", "brick-wg4-128chunks"])
+                              "brick-contiguous", "brick-tilewise", "brick-wg4-static64"])
 @pytest.mark.parametrize("cam", ["K1", "K2", "-x", "-y", "-z"])
 def test_kernel_variants_bit_identical(variant, cam):
     """Every kernel variant (LDS bricks on/off, span vs simple march, tile shapes, workgroup size,
