@@ -1,0 +1,82 @@
+"""bench.py's workload descriptions (no GPU): the geometry of BASELINE configs 2, 4 and 5 as the bench and the
+full-size GPU tests build them, the fly-through path, and the stamp that ties `roofline.traffic` to a kernel build."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sub_volume_renderer_amd import synth  # noqa: E402
+
+
+class _Shape:
+    def __init__(self, n, dtype):
+        self.shape, self.ndim, self.dtype = (n, n, n), 3, np.dtype(dtype)
+
+
+def _pairs(n):
+    return [(_Shape(n >> k, np.uint8), _Shape(n >> k, np.uint32)) for k in range(3)]
+
+
+def test_config2_geometry_is_surveys_8d():
+    spec = bench.config2_spec(1024, 1920, 1080, "K1", _pairs(1024))
+    assert spec.chunk_shapes == [(16, 16, 48), (8, 8, 48), (4, 4, 48)]
+    assert spec.ring_shapes == [(32, 32, 11), (64, 64, 11), (64, 64, 6)]
+    rings = [tuple(a * b for a, b in zip(r, c)) for r, c in zip(spec.ring_shapes, spec.chunk_shapes)]
+    assert rings == [(512, 512, 528), (512, 512, 528), (256, 256, 288)]
+    (centre, sizes), = spec.centers
+    assert sizes == [(496, 496, 480), (512, 512, 512), (256, 256, 256)]        # LOD0 default (N-1)*C, LOD1/2 whole level
+    assert centre == (511.5, 511.5, 511.5)
+    m = spec.material
+    assert (m["lmip_threshold"], m["fog_density"], len(m["colors"])) == (0.5 * 255.0, 0.01, 4)
+    # camera K1: 1.6 N from the centre along normalize(-0.80, 0.36, 0.48)
+    d = np.array(spec.cam_position) - 511.5
+    np.testing.assert_allclose(d / np.linalg.norm(d), np.array([-0.80, 0.36, 0.48]) / np.linalg.norm([-0.80, 0.36, 0.48]), atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(d), 1.6 * 1024)
+
+
+def test_config5_is_config2_scaled_by_two_with_its_material():
+    spec = bench.config5_spec(2048, 1920, 1080, "K1", _pairs(2048))
+    assert spec.ring_shapes == [(64, 64, 22), (128, 128, 22), (128, 128, 12)]
+    m = spec.material
+    assert m["lmip_threshold"] == 0.3 * 255.0 and m["fog_density"] == 0.05 and len(m["colors"]) == 256
+    assert [c[0] for c in m["colors"][:3]] == [0.0, 1 / 256, 2 / 256]
+    assert spec.centers[0][1][1:] == [(1024,) * 3, (512,) * 3]
+
+
+def test_config4_is_lazy_and_its_path_moves_two_voxels_per_frame():
+    spec = bench.config4_spec(4096, 1920, 1080)
+    assert [type(d).__name__ for d, _ in spec.pairs] == ["LazyLod"] * 3
+    assert [d.shape for d, _ in spec.pairs] == [(4096,) * 3, (2048,) * 3, (1024,) * 3]
+    assert spec.pairs[0][0].dtype == np.uint8 and spec.pairs[0][1].dtype == np.uint32
+    assert spec.ring_shapes == [(32, 32, 11), (64, 64, 11), (64, 64, 6)] and spec.centers == [(spec.cam_position, None)]
+    poses = bench.flythrough_poses(spec, 240)
+    assert len(poses) == 240 and poses[0][0] == tuple(np.array(spec.cam_position, float))
+    step = np.array(poses[1][0]) - np.array(poses[0][0])
+    np.testing.assert_allclose(np.linalg.norm(step), 2.0)
+    np.testing.assert_allclose(np.array(poses[239][0]) - np.array(poses[0][0]), 239 * step, atol=1e-9)
+    view = np.array(poses[0][1]) - np.array(poses[0][0])
+    np.testing.assert_allclose(np.cross(view, step), 0, atol=1e-9)           # along the view direction
+    # a block of the never-resident volume is what the closed form says
+    d = spec.pairs[1][0][(slice(100, 104), slice(8, 12), slice(48, 96))]
+    np.testing.assert_array_equal(d, synth.block(4096, 1, (100, 8, 48), (4, 4, 48))[0])
+
+
+def test_kernel_source_hash_covers_the_march_sources_and_traffic_is_stamped():
+    import json
+
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", bench.PROFILE_ROUND, "traffic.json")
+    assert os.path.exists(path), "tools/profile_bench.sh writes it; copy it into profiles/<round>/"
+    doc = json.load(open(path))
+    assert {"config", "n", "width", "height", "camera", "variant", "ring_storage", "kernel_source_sha16"} <= set(doc["workload"])
+    assert doc["traffic_bytes_per_launch"] == int(doc["FETCH_SIZE_KB"] * 1024 * 2 + doc["WRITE_SIZE_KB"] * 1024)
+    # the committed figure belongs to the committed kernel (a kernel edit without a new profile would fail here)
+    assert doc["workload"]["kernel_source_sha16"] == h, "march kernel changed since profiles/%s/traffic.json was taken" % bench.PROFILE_ROUND
+
+
+def test_summarise():
+    s = bench.summarise([3.0, 1.0, 2.0])
+    assert s == {"n": 3, "median_ms": 2.0, "min_ms": 1.0, "max_ms": 3.0}
