@@ -23,6 +23,8 @@ vol, cam = scene.volume, scene.camera
 vol.material.lmip_threshold = 0.0
 for world, collective in ((8, True), (8, False), (1, False)):
     tiled = TiledFrame(W, H, 0, 1, 16, force_collective=collective)
+    if collective and os.environ.get("SVR_HOSTFLOOR_TRANSPORT", "svr") == "svr":
+        print("init_comm:", tiled.init_comm(vol), tiled.transport, flush=True)
     region = TiledFrame(W, H, 0, world, 16).region if not collective else tiled.region
     if collective:                                   # bands of an 8-rank tiling would need 8 ranks; use this rank's full band set
         region = tiled.region
