@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Strong-scaling rehearsal on ONE GPU: time the band set of every rank of a world of 1/2/4/8 ranks
 (TiledFrame regions) and print the frame time a node of that many GPUs would reach (max over ranks,
-without the gather).  usage: exp_tiles.py [camera] [band_h] [variant]"""
+without the gather), for interleaved row bands and for the most square grid of tiles (8 ranks: config 3's 2x4).
+usage: exp_tiles.py [camera] [band_h] [variant]"""
 import ctypes as C
 import os
 import sys
@@ -22,13 +23,13 @@ pairs = [synth.volume(n, k, 4096, xp=torch, device=dev, slab=16) for k in range(
 scene = testing.build(bench.config2_spec(n, W, H, camname, pairs))
 vol, cam = scene.volume, scene.camera
 N.check(N.lib().svr_set_variant(vol._rings.handle, variant), "variant")
-for mode in ("full", "lmip"):
+for mode, tiling in (("full", "rows"), ("full", "grid"), ("lmip", "rows"), ("lmip", "grid")):
     vol.material.lmip_threshold = float("inf") if mode == "full" else 127.5
     base = None
     for world in (1, 2, 4, 8):
         times = []
         for rank in range(world):
-            tf = TiledFrame(W, H, rank, world, band_h)
+            tf = TiledFrame(W, H, rank, world, band_h, tiling=tiling)
             r = vol.render(cam, W, H, region=tf.region)
             torch.cuda.synchronize()
             vol.prepare()
@@ -40,4 +41,5 @@ for mode in ("full", "lmip"):
             times.append(ms.value)
         t = max(times)
         base = base or t
-        print(f"{camname} {mode} band_h={band_h} world={world}: max {t:.4f} ms  min {min(times):.4f} ms  speedup {base/t:.2f}x", flush=True)
+        what = f"band_h={band_h}" if tiling == "rows" else "grid " + ("x".join(str(v) for v in TiledFrame(W, H, 0, world, tiling=tiling).grid[:2]) if world > 1 else "1x1")
+        print(f"{camname} {mode} {what} world={world}: max {t:.4f} ms  min {min(times):.4f} ms  speedup {base/t:.2f}x", flush=True)
