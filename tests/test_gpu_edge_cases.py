@@ -134,3 +134,30 @@ def test_c_abi_rejects_bad_arguments_with_messages():
     m = N.Material()
     fails(lib.svr_set_material(ctx, C.byref(m)), "at least one colour")
     assert lib.svr_destroy(ctx) == 0
+
+
+@pytest.mark.parametrize("W,H,world,tiling", [(1920, 1080, 8, "2x4"), (66, 45, 6, "3x2"), (64, 48, 4, "rows"), (65, 45, 3, "rows")])
+def test_untile_kernels_equal_the_host_permutation(W, H, world, tiling):
+    """svr_untile_grid / svr_untile_stripes on gathered buffers of every plane type (RGBA f32, depth f32, label
+    i32, flags u8) against TiledFrame's own CPU un-tiling."""
+    import torch
+
+    from sub_volume_renderer_amd import WrappingBuffer
+    from sub_volume_renderer_amd.distributed import TiledFrame
+
+    class Holder:                                           # un-tiling only needs a device context
+        def __init__(self):
+            z = np.zeros((8, 8, 8), np.uint8)
+            self._rings = WrappingBuffer(z, z, (2, 2, 2), (4, 4, 4)).rings
+            self._rings.handle
+
+    holder = Holder()
+    tf = TiledFrame(W, H, 0, world, 8, tiling=tiling)
+    g = torch.Generator().manual_seed(W + world)
+    for dtype, tail in ((torch.float32, (4,)), (torch.float32, ()), (torch.int32, ()), (torch.uint8, ())):
+        shape = (world, tf.rows_per_rank, tf.cols_per_rank, *tail)
+        gathered = (torch.rand(shape, generator=g) * 200).to(dtype)
+        want = tf.untile(gathered, torch.zeros((H, W, *tail), dtype=dtype))
+        got = tf.untile(gathered.cuda(), torch.zeros((H, W, *tail), dtype=dtype, device="cuda"), holder)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want), (dtype, tail)
