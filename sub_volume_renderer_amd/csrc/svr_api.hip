@@ -906,6 +906,27 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.skip_flags = skip_flags_env;
     P.cells_all = skip ? c->cells_dil_all : nullptr;
     P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;
+    if (!brick_bytes_env && !skip) {
+        // When a pixel is wider than about 1.5 finest-level voxels at the volume's centre (a 2048^3 volume seen
+        // whole at 1080p: 1.8), the 64 rays of a wave are that far apart and the box of even a short slab outgrows
+        // 8 KiB; 16 KiB per wave (10 waves per CU) then wins: config 5, K1, full mode 5.28 -> 4.70 ms.  Not while
+        // empty-space skipping is active: its cell tests want the occupancy (config 5 LMIP: 0.80 ms at 8 KiB, 1.08 at 16)
+        // (32 KiB: 5.61, 64 KiB: 9.35; at config 2's 0.9 voxels per pixel 16 KiB loses 20 %).
+        const float centre[4] = { 0.5f * P.size[0] - 0.5f, 0.5f * P.size[1] - 0.5f, 0.5f * P.size[2] - 0.5f, 1.0f };
+        float w[4], q[4];
+        mat_vec4(cam->world, centre, w);
+        mat_vec4(P.pc, w, q);
+        if (q[3] > 0.0f) {
+            const float a[4] = { q[0] / q[3], q[1] / q[3], q[2] / q[3], 1.0f };
+            const float b[4] = { a[0] + 2.0f / (float)fr->frame_w, a[1], a[2], 1.0f };
+            float da[4], db[4];
+            mat_vec4(P.ndc_to_data, a, da);
+            mat_vec4(P.ndc_to_data, b, db);
+            float d2 = 0.0f;
+            for (int k = 0; k < 3; ++k) { const float d = db[k] / db[3] - da[k] / da[3]; d2 += d * d; }
+            if (d2 >= 2.25f && d2 < 1e12f) P.brick_bytes = 16384;
+        }
+    }
     P.density_all = c->density_all;
     P.span_ok = span_addressable(c) ? 1 : 0;
     P.per_lod_rsrc = c->density_all_bytes >= ((size_t)1 << 32) ? 1 : 0;
