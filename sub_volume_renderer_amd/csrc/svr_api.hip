@@ -2,9 +2,13 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "svr_internal.h"
@@ -344,27 +348,84 @@ static void pack_row_range(const char* src, size_t es, const int64_t st[3], cons
 }
 
 // The host half of an upload is a gather of short rows (48 .. 528 voxels) out of a large strided array into the
-// pinned staging slot: one core moves ~6-10 GB/s that way, well under the PCIe rate, so the rows are dealt to a
-// few threads (contiguous row ranges; short-lived threads: a slot is tens of MiB, thread start-up is noise).
-static void pack_rows(const char* src, size_t es, const int64_t st[3], const int32_t shape[3],
-                      int64_t r0, int64_t r1, char* dst) {
-    const size_t row = (size_t)shape[0] * es;
-    const int64_t nrows = r1 - r0;
-    const size_t bytes = row * (size_t)nrows;
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes / ((size_t)2 << 20));
-    if (const char* e = getenv("SVR_PACK_THREADS")) nt = std::max(1, atoi(e));
-    if (nt <= 1 || nrows < 2 * nt) { pack_row_range(src, es, st, shape, r0, r1, dst); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)nt - 1);
-    const int64_t per = (nrows + nt - 1) / nt;
-    for (int t = 1; t < nt; ++t) {
-        const int64_t a = r0 + per * t, b = std::min(r1, a + per);
-        if (a >= b) break;
-        pool.emplace_back(pack_row_range, src, es, st, shape, a, b, dst + (size_t)(a - r0) * row);
+// pinned staging slot: one core moves ~6-15 GB/s that way, well under the PCIe rate, so the rows are dealt to a
+// few threads (contiguous row ranges).  The threads are kept: a block is a few MiB to tens of MiB, i.e. 0.1-1 ms
+// of copying, and starting 7 threads per block costs a good part of that.
+class PackPool {
+public:
+    static PackPool& get() {
+        static std::mutex mu;
+        static PackPool* pool = nullptr;
+        static pid_t owner = 0;
+        std::lock_guard<std::mutex> g(mu);
+        if (!pool || owner != getpid()) { pool = new PackPool(); owner = getpid(); }   // threads do not survive fork(): the child starts its own (the parent's object is left alone)
+        return *pool;
     }
-    pack_row_range(src, es, st, shape, r0, std::min(r1, r0 + per), dst);
-    for (auto& th : pool) th.join();
+    static constexpr int kMax = 16;
+    // fn(t) for t in [0, nt): t = 0 on the caller, the rest on the workers; returns when all are done
+    void run(int nt, const std::function<void(int)>& fn) {
+        nt = std::min(nt, kMax);
+        if (nt <= 1) { fn(0); return; }
+        std::lock_guard<std::mutex> one(run_mu);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            while ((int)workers.size() < nt - 1) { const int id = (int)workers.size() + 1; workers.emplace_back([this, id] { loop(id); }); }
+            job = &fn; want = nt; left = nt - 1; ++gen;
+        }
+        go.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu);
+        done.wait(g, [this] { return left == 0; });
+        job = nullptr;
+    }
+    ~PackPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        go.notify_all();
+        for (auto& w : workers) w.join();
+    }
+private:
+    void loop(int id) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> g(mu);
+        for (;;) {
+            go.wait(g, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (id >= want) continue;
+            const std::function<void(int)>* f = job;
+            g.unlock();
+            (*f)(id);
+            g.lock();
+            if (--left == 0) done.notify_one();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu, run_mu;
+    std::condition_variable go, done;
+    const std::function<void(int)>* job = nullptr;
+    uint64_t gen = 0;
+    int want = 0, left = 0;
+    bool stop = false;
+};
+
+// Pack rows [r0, r1) of the density block and of the label block (either may be absent) in one parallel pass.
+static void pack_rows(const char* dsrc, size_t des, const int64_t* dst_strides, char* ddst,
+                      const char* lsrc, size_t les, const int64_t* lst_strides, char* ldst,
+                      const int32_t shape[3], int64_t r0, int64_t r1) {
+    const int64_t nrows = r1 - r0;
+    const size_t bytes = (size_t)shape[0] * (size_t)nrows * ((dsrc ? des : 0) + (lsrc ? les : 0));
+    unsigned hw = std::thread::hardware_concurrency();
+    // (12 or 16 threads, and streaming stores into the slot, measured no faster)
+    int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes / ((size_t)512 << 10));
+    if (const char* e = getenv("SVR_PACK_THREADS")) nt = std::max(1, atoi(e));
+    nt = (int)std::min<int64_t>(std::max(nt, 1), std::max<int64_t>(1, nrows / 2));
+    const int64_t per = (nrows + nt - 1) / nt;
+    PackPool::get().run(nt, [&](int t) {
+        const int64_t a = r0 + per * t, b = std::min(r1, a + per);
+        if (a >= b) return;
+        if (dsrc) pack_row_range(dsrc, des, dst_strides, shape, a, b, ddst + (size_t)(a - r0) * shape[0] * des);
+        if (lsrc) pack_row_range(lsrc, les, lst_strides, shape, a, b, ldst + (size_t)(a - r0) * shape[0] * les);
+    });
 }
 
 int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32_t shape[3],
@@ -399,7 +460,12 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     // after the density block, 16-byte aligned.
     const size_t row_bytes = (size_t)shape[0] * (des + les);
     SVR_REQUIRE(row_bytes + 32 <= c->slot_bytes, "svr_upload_region: one row of the region exceeds the staging slot");
-    const int64_t rows_max = (int64_t)((c->slot_bytes - 32) / row_bytes);
+    // Blocks of about an eighth of the region (4 MiB .. one slot): the pack of block k+1 runs while block k is on
+    // the bus and block k-1 is being scattered, so a region of one or two slots' worth still overlaps the three.
+    const size_t region_bytes = row_bytes * (size_t)shape[1] * (size_t)shape[2];
+    size_t block_bytes = std::min(c->slot_bytes - 32, std::max<size_t>((size_t)4 << 20, region_bytes / 8));
+    if (const char* e = getenv("SVR_UPLOAD_BLOCK_MIB")) block_bytes = std::min(c->slot_bytes - 32, std::max<size_t>(1, (size_t)atoi(e)) << 20);
+    const int64_t rows_max = std::max<int64_t>(1, (int64_t)(block_bytes / row_bytes));
     const int64_t plane_rows = shape[1];
     const int64_t total_rows = plane_rows * shape[2];
     for (int64_t r0 = 0; r0 < total_rows;) {
@@ -415,8 +481,8 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
         const size_t dbytes = (size_t)shape[0] * (size_t)nrows * des;
         const size_t lofs = (dbytes + 15) & ~(size_t)15;
         const size_t lbytes = (size_t)shape[0] * (size_t)nrows * les;
-        if (density) pack_rows(static_cast<const char*>(density), des, density_strides, shape, r0, r1, static_cast<char*>(S.host));
-        if (labels) pack_rows(static_cast<const char*>(labels), les, labels_strides, shape, r0, r1, static_cast<char*>(S.host) + lofs);
+        pack_rows(static_cast<const char*>(density), des, density_strides, static_cast<char*>(S.host),
+                  static_cast<const char*>(labels), les, labels_strides, static_cast<char*>(S.host) + lofs, shape, r0, r1);
         SVR_HIP_TRY(hipMemcpyAsync(S.dev, S.host, lofs + lbytes, hipMemcpyHostToDevice, c->upload_stream));
         // the staged block as a box of the ring
         const int32_t z0 = (int32_t)(r0 / plane_rows), y0 = (int32_t)(r0 % plane_rows);
