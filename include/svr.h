@@ -27,7 +27,7 @@ extern "C" {
 
 #define SVR_MAX_LODS 8
 #define SVR_MAX_CLIP_PLANES 8
-#define SVR_ABI_VERSION 5
+#define SVR_ABI_VERSION 6
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -92,7 +92,20 @@ typedef struct svr_material {
     uint32_t clipping_plane_count; /* 0 .. SVR_MAX_CLIP_PLANES */
     int32_t  clipping_mode_all;
     const float* clipping_planes;  /* host pointer, clipping_plane_count * 4 floats (may be NULL when the count is 0) */
+    /* Which raycast runs (FUTURE.md:111-120 "swappable rendering pipeline": a material-level switch).
+     * SVR_MODE_LMIP: raycast.wgsl as it stands (MIP is LMIP with threshold -inf, fall-off 0 and no sample limit).
+     * SVR_MODE_WEIGHTED_AVERAGE: the mode FUTURE.md:97-109 asks for and leaves without a formula; defined HERE
+     * (oracle twin: oracle/lmip_oracle.c `raycast_weighted_average`) as
+     *     d_i = f32(i) * |step|          distance of sample i from the ray's entry, in the units of the fog distance
+     *     t_i = max(1 - weight_falloff * d_i, 0),  w_i = t_i * t_i
+     *     value = (sum w_i * s_i) / (sum w_i)      over the samples of the ray, in order, f32
+     * shown at the sample with the largest w_i * |s_i| (first one wins; it gives depth, label and fog distance);
+     * nothing but zeros along the ray: a miss.  The ray ends at the first sample with t_i == 0. */
+    int32_t  render_mode;          /* svr_render_mode */
+    float    weight_falloff;       /* >= 0; only read in SVR_MODE_WEIGHTED_AVERAGE */
 } svr_material;
+
+typedef enum svr_render_mode { SVR_MODE_LMIP = 0, SVR_MODE_WEIGHTED_AVERAGE = 1 } svr_render_mode;
 
 /* == the six mat4 of u_stdinfo / u_wobject that the shaders read
  * (vs_main.wgsl:18-22, fs_main.wgsl:62-63) + u_wobject.volume_dimensions

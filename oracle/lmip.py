@@ -40,6 +40,7 @@ class _Material(C.Structure):
         ("fog_density", C.c_float), ("fog_color", C.c_float * 3), ("color_count", C.c_uint32),
         ("colors", C.POINTER(C.c_float)), ("colorspace_srgb", C.c_int32),
         ("clipping_plane_count", C.c_uint32), ("clipping_mode_all", C.c_int32), ("clipping_planes", C.POINTER(C.c_float)),
+        ("render_mode", C.c_int32), ("weight_falloff", C.c_float),
     ]
 
 
@@ -96,7 +97,7 @@ def _mat(m):
 DEFAULT_MATERIAL = dict(lmip_fall_off=0.5, lmip_max_samples=10, fog_density=0.5, fog_color=(0.5, 0.5, 0.5),
                         colors=None, clim=(0, 1), gamma=1.0, opacity=1.0,       # _material.py:26-37
                         clipping_planes=(), clipping_mode="ANY",                # pygfx Material defaults
-                        render_mode="lmip")
+                        render_mode="lmip", weight_falloff=0.5)
 DEFAULT_COLORS = [(0.0, 1.0, 1.0), (0.25, 1.0, 1.0), (0.5, 1.0, 1.0), (0.75, 1.0, 1.0)]  # _material.py:51-57
 
 
@@ -117,6 +118,8 @@ def render(rings, matrices, volume_dimensions_shader, material, width, height, r
         # the first sample is significant (|s| >= -inf), every larger one replaces it (strict >, :50), and the
         # loop never breaks (:58: since < 2^31 - 1, |s| < max * 0 is false).  lmip_numpy.py states MIP directly.
         cm.lmip_threshold, cm.lmip_fall_off, cm.lmip_max_samples = float("-inf"), 0.0, 2**31 - 1
+    cm.render_mode = 1 if m["render_mode"] == "weighted_average" else 0      # svr_render_mode (include/svr.h)
+    cm.weight_falloff = float(m["weight_falloff"])
     cm.fog_color[:] = [float(v) for v in m["fog_color"]]
     cm.color_count = len(col)
     cm.colors = col.ctypes.data_as(C.POINTER(C.c_float))

@@ -120,8 +120,42 @@ def _render(rings, M, vdim, mat, W, H, srgb, pick_id=None):
             done |= inb
         return val
 
-    mip = str(mat.get("render_mode", "lmip")) == "mip"
+    mode = str(mat.get("render_mode", "lmip"))
+    mip = mode == "mip"
+    wavg = mode == "weighted_average"
     it = 0
+    if wavg:
+        # SVR_MODE_WEIGHTED_AVERAGE (include/svr.h; this project's definition, the reference has none):
+        # w = max(1 - k d, 0)^2, value = sum(w s) / sum(w), shown at the first sample with the largest w |s|
+        k = f32(mat.get("weight_falloff", 0.5))
+        steplen = np.sqrt((step[0] * step[0] + step[1] * step[1]) + step[2] * step[2])
+        num = np.zeros((H, W), f32)
+        den = np.zeros((H, W), f32)
+        best = np.zeros((H, W), f32)
+        going = frag.copy()
+        while True:
+            tw = f32(1.0) - k * (f32(it) * steplen)
+            going &= (it < nsteps) & (tw > 0)
+            if not going.any():
+                break
+            idx = np.nonzero(going)
+            off = [f32(it) * step[k_][idx] for k_ in range(3)]
+            coord = [start[k_][idx] + off[k_] for k_ in range(3)]
+            s = texel_index(coord, labels=False)
+            steps[idx] += 1
+            w = tw[idx] * tw[idx]
+            num[idx] = num[idx] + w * s
+            den[idx] = den[idx] + w
+            contribution = w * np.abs(s)
+            better = contribution > best[idx]
+            best[idx] = np.where(better, contribution, best[idx])
+            for k_ in range(3):
+                hit_off[k_][idx] = np.where(better, off[k_], hit_off[k_][idx])
+                hit_coord[k_][idx] = np.where(better, coord[k_], hit_coord[k_][idx])
+            it += 1
+        found = best > 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            samp = np.where(found, num / den, f32(0.0)).astype(f32)
     while mip:
         # MIP stated directly (not through the LMIP state machine): the largest |sample| of the whole ray,
         # first occurrence; every fragment "finds" one (its first sample starts the running maximum)
@@ -142,7 +176,7 @@ def _render(rings, M, vdim, mat, W, H, srgb, pick_id=None):
             hit_coord[k][idx] = np.where(better, coord[k], hit_coord[k][idx])
         found[idx] = True
         it += 1
-    while not mip:
+    while not (mip or wavg):
         act = ~finished & (it < nsteps)
         if not act.any():
             break

@@ -236,6 +236,29 @@ static int shade_pixel(const frame_ctx* F, int W, int H, int i, int j,
     v3 local_max_offset = { 0, 0, 0 }, local_max_coord = { 0, 0, 0 };
     int found = 0, since = 0;
     uint32_t executed = 0;
+    if (M->render_mode == SVR_MODE_WEIGHTED_AVERAGE) {
+        /* NOT in the reference: FUTURE.md:97-109 names a "weighted average" mode ("weight each sample by
+         * distance", "sampling a finite number of points based on distance") and gives no formula.  The
+         * definition is this project's (include/svr.h, SVR_MODE_WEIGHTED_AVERAGE); this loop is its CPU twin and
+         * keeps the ray, the sample positions and the LOD fall-through of raycast.wgsl:29-32. */
+        float steplen = length3(step);
+        float num = 0.0f, den = 0.0f, best = 0.0f;
+        for (float iter = 0.0f; iter < nstepsf; iter = iter + 1.0f) {
+            float tw = 1.0f - M->weight_falloff * (iter * steplen);
+            if (!(tw > 0.0f)) break;
+            ++executed;
+            v3 offset = { iter * step.x, iter * step.y, iter * step.z };
+            v3 coord = { start.x + offset.x, start.y + offset.y, start.z + offset.z };
+            float sample = sample_vol(F->n, F->lods, coord, sizef);
+            float w = tw * tw;
+            num = num + w * sample;
+            den = den + w;
+            float contribution = w * fabsf(sample);
+            if (contribution > best) { best = contribution; local_max_offset = offset; local_max_coord = coord; }
+        }
+        found = best > 0.0f;
+        local_max_sample = found ? num / den : 0.0f;
+    } else
     for (float iter = 0.0f; iter < nstepsf; iter = iter + 1.0f) {                 /* :29 */
         ++executed;
         v3 offset = { iter * step.x, iter * step.y, iter * step.z };              /* :30 */

@@ -74,6 +74,7 @@ class SubVolumeMaterial:
         self.clipping_planes = ()
         self.clipping_mode = "ANY"
         self.render_mode = "lmip"
+        self.weight_falloff = 0.5
         arguments = dict(clim=clim, gamma=gamma, opacity=opacity, lmip_threshold=lmip_threshold,
                          lmip_fall_off=lmip_fall_off, lmip_max_samples=lmip_max_samples, fog_density=fog_density,
                          fog_color=fog_color,
@@ -150,7 +151,7 @@ class SubVolumeMaterial:
         self._store("clipping_mode", mode)
 
     # -- render mode: the swappable raycast the reference wishes for (FUTURE.md:97-120) -------------------------
-    RENDER_MODES = ("lmip", "mip")
+    RENDER_MODES = ("lmip", "mip", "weighted_average")
 
     @property
     def render_mode(self) -> str:
@@ -158,7 +159,12 @@ class SubVolumeMaterial:
         what pygfx's own ``VolumeMipMaterial`` raycast selects (without its sub-step refinement).  MIP is the
         LMIP state machine with every sample significant, no fall-off and no sample limit, so it runs on the
         same kernel: the draw sends threshold = -inf, fall_off = 0, max_samples = 2**31 - 1 and leaves the
-        ``lmip_*`` properties untouched."""
+        ``lmip_*`` properties untouched.
+
+        "weighted_average": the mode FUTURE.md:97-109 wishes for ("weight each sample by distance ... sampling a
+        finite number of points based on distance") and gives no formula for; defined in ``include/svr.h``
+        (``SVR_MODE_WEIGHTED_AVERAGE``): sample i weighs ``max(1 - weight_falloff * d_i, 0) ** 2``, the pixel shows
+        the weighted mean of the ray's samples at the sample that contributes most."""
         return self._u["render_mode"]
 
     @render_mode.setter
@@ -167,6 +173,20 @@ class SubVolumeMaterial:
         if mode not in self.RENDER_MODES:
             raise ValueError(f"render_mode must be one of {self.RENDER_MODES}, not {mode!r}")
         self._store("render_mode", mode)
+
+    @property
+    def weight_falloff(self) -> float:
+        """"weighted_average" mode: how fast a sample's weight falls with its distance d from the ray's entry
+        into the volume (d in the fog's unit: 1 = one volume edge); samples at d >= 1 / weight_falloff weigh
+        nothing and are not taken.  0 = plain mean of the whole ray."""
+        return float(self._u["weight_falloff"])
+
+    @weight_falloff.setter
+    def weight_falloff(self, value) -> None:
+        value = float(value)
+        if not (0.0 <= value < float("inf")):
+            raise ValueError(f"weight_falloff must be finite and >= 0, not {value!r}")
+        self._store("weight_falloff", np.float32(value))
 
     def lmip_uniforms(self) -> tuple[float, float, int]:
         """(threshold, fall_off, max_samples) as the draw sends them for the current render mode."""

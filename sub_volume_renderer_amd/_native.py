@@ -62,7 +62,12 @@ class Material(C.Structure):
         ("clipping_plane_count", C.c_uint32),
         ("clipping_mode_all", C.c_int32),
         ("clipping_planes", C.POINTER(C.c_float)),
+        ("render_mode", C.c_int32),
+        ("weight_falloff", C.c_float),
     ]
+
+
+SVR_MODE_LMIP, SVR_MODE_WEIGHTED_AVERAGE = 0, 1
 
 
 class Camera(C.Structure):

@@ -330,6 +330,8 @@ class SubVolume(_HasWorld):
         cm.clipping_plane_count = int(planes.shape[0])
         cm.clipping_mode_all = 1 if u["clipping_mode"] == "ALL" else 0
         cm.clipping_planes = planes.ctypes.data_as(C.POINTER(C.c_float))
+        cm.render_mode = N.SVR_MODE_WEIGHTED_AVERAGE if u["render_mode"] == "weighted_average" else N.SVR_MODE_LMIP
+        cm.weight_falloff = float(u["weight_falloff"])
         N.check(N.lib().svr_set_material(self._rings.handle, C.byref(cm)), "svr_set_material")
         self._material_version_pushed = m._version
 

@@ -42,7 +42,11 @@ Rccl& rccl() {
         for (const char* n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char* n : names) if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!r.handle) { r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!r.handle) {
+            const char* why = dlerror();               // one call: dlerror() clears the message it returns
+            r.error = std::string("librccl not found: ") + (why ? why : "no loader message");
+            return;
+        }
         auto sym = [&](const char* name) {
             void* p = dlsym(r.handle, name);
             if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + name;

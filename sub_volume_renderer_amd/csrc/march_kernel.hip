@@ -304,6 +304,55 @@ __global__ __launch_bounds__(256) void march_simple(const MarchParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// SVR_MODE_WEIGHTED_AVERAGE (include/svr.h; FUTURE.md:97-109 names the mode, the formula is this project's):
+// every sample weighs w = max(1 - k d, 0)^2 with d its distance from the ray's entry (the unit of the fog
+// distance, fs_main.wgsl:82); the pixel shows sum(w s) / sum(w) at the sample with the largest w |s|.
+// Same ray, same sample positions and the same LOD fall-through as raycast.wgsl:29-32; sums in sample order, so
+// the CPU twin (oracle/lmip_oracle.c raycast_weighted_average) reproduces every bit.  One texel fetch per
+// step from global memory, like march_simple.
+// ---------------------------------------------------------------------------
+template <int NL, bool COUNT>
+__global__ __launch_bounds__(256) void march_wavg(const MarchParams P) {
+    const int nblocks = P.tiles_x * P.tiles_y;
+    const int t = P.tile_order ? (int)P.tile_order[blockIdx.x] : xcd_remap((int)blockIdx.x, nblocks);
+    const int tile_x = t % P.tiles_x, tile_y = t / P.tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int r = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (c >= P.frame.out_w || r >= P.frame.out_h) return;
+    const size_t o = (size_t)r * (size_t)P.frame.out_w + (size_t)c;
+    const int x = P.frame.x0 + c;
+    const int y = P.frame.y0 + (r / P.frame.band_h) * P.frame.band_pitch + (r % P.frame.band_h);
+
+    Ray R; Hit h;
+    h.found = false; h.sample = 0.f; h.steps = 0u;
+    h.offset = { 0.f, 0.f, 0.f }; h.coord = { 0.f, 0.f, 0.f };
+    bool frag = (x < P.frame.frame_w && y < P.frame.frame_h) && setup_ray(P, x, y, R);
+    if (frag) {
+        const float steplen = sqrtf(dot3(R.step, R.step));
+        float num = 0.f, den = 0.f, best = 0.f;
+        const float nstepsf = (float)R.nsteps;
+        for (float iter = 0.0f; iter < nstepsf; iter = iter + 1.0f) {
+            const float tw = 1.0f - P.weight_falloff * (iter * steplen);
+            if (!(tw > 0.0f)) break;                                                   // this sample and all later ones weigh nothing
+            if (COUNT) ++h.steps;
+            f3 off = { iter * R.step.x, iter * R.step.y, iter * R.step.z };            // raycast.wgsl:30
+            f3 coord = { R.start.x + off.x, R.start.y + off.y, R.start.z + off.z };    // :31
+            const float s = sample_density<NL>(P, coord.x, coord.y, coord.z);          // :32
+            const float w = tw * tw;
+            num = num + w * s;
+            den = den + w;
+            const float contribution = w * fabsf(s);
+            if (contribution > best) { best = contribution; h.offset = off; h.coord = coord; }
+        }
+        h.found = best > 0.0f;
+        h.sample = h.found ? num / den : 0.0f;
+    }
+    shade_and_store<NL>(P, o, frag, h);
+    if (COUNT && P.steps) P.steps[o] = h.steps;
+}
+
+// ---------------------------------------------------------------------------
 // Variant 0 (default): span march.
 //
 // Exactness argument.  For one ray and one axis, the voxel index the reference
@@ -1126,7 +1175,10 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     const bool simple = kind == 1 || !p.span_ok;                 // rings the 32-bit / 24-bit addressing of the span kernel cannot reach
-    if (simple) {
+    if (p.render_mode == SVR_MODE_WEIGHTED_AVERAGE) {
+        if (p.steps) hipLaunchKernelGGL((march_wavg<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
+        else         hipLaunchKernelGGL((march_wavg<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
+    } else if (simple) {
         if (p.steps) hipLaunchKernelGGL((march_simple<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_simple<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else {

@@ -215,6 +215,9 @@ int svr_set_material(svr_ctx* c, const svr_material* m) {
     SVR_REQUIRE(m->color_count >= 1 && m->colors, "svr_set_material: at least one colour is required");
     SVR_REQUIRE(m->clipping_plane_count <= SVR_MAX_CLIP_PLANES, "svr_set_material: too many clipping planes");
     SVR_REQUIRE(m->clipping_plane_count == 0 || m->clipping_planes, "svr_set_material: clipping_planes is null");
+    SVR_REQUIRE(m->render_mode == SVR_MODE_LMIP || m->render_mode == SVR_MODE_WEIGHTED_AVERAGE, "svr_set_material: unknown render_mode");
+    SVR_REQUIRE(m->render_mode != SVR_MODE_WEIGHTED_AVERAGE || (m->weight_falloff >= 0.0f && m->weight_falloff < INFINITY),
+                "svr_set_material: weight_falloff must be finite and >= 0");
     DeviceGuard guard(c->device);
     const size_t ncol = (size_t)m->color_count * 4;
     const bool same_colors = c->material_set && c->colors_host.size() == ncol &&
@@ -861,6 +864,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     for (uint32_t k = 0; k < m.clipping_plane_count; ++k)
         for (int a = 0; a < 4; ++a) P.clip[k][a] = c->clip_host[4 * k + a];
     P.lmip_max_samples = m.lmip_max_samples; P.fog_density = m.fog_density;
+    P.render_mode = m.render_mode; P.weight_falloff = m.weight_falloff;
     for (int a = 0; a < 3; ++a) P.fog_color[a] = m.fog_color[a];
     P.color_count = m.color_count; P.colors = c->colors_dev; P.colorspace_srgb = m.colorspace_srgb;
     P.num_lods = c->num_lods;
@@ -873,7 +877,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
     int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;
     if (lw > 6) lw = 6;
-    if ((c->variant & 3) == 1) lw = 3;                        // the simple kernel is 8x8 only
+    const bool wavg = m.render_mode == SVR_MODE_WEIGHTED_AVERAGE;  // its own kernel, laid out like the simple one
+    if ((c->variant & 3) == 1 || wavg) lw = 3;                // the simple kernel is 8x8 only
     P.tile_log2w = lw;
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
@@ -899,7 +904,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     // kernel kind 0: span march, one wave per block; 2: span march, 2 x 2 waves per block; 1: simple (2 x 2)
     // (rings of 4 GiB or more fall back to the simple kernel's 64-bit addressing, see launch_nl)
-    P.block_waves_log2 = ((c->variant & 3) == 0 && span_addressable(c)) ? 0 : 1;
+    P.block_waves_log2 = ((c->variant & 3) == 0 && span_addressable(c) && !wavg) ? 0 : 1;
     const int bw = (1 << P.block_waves_log2) << lw, bh = (1 << P.block_waves_log2) * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)

@@ -54,6 +54,8 @@ struct MarchParams {
     float lmip_threshold, lmip_fall_off;
     uint32_t lmip_threshold_raw;   // integer rings: smallest value v with (float)v >= lmip_threshold (max + 1: none)
     int32_t lmip_max_samples;
+    int32_t render_mode;           // svr_render_mode
+    float weight_falloff;          // SVR_MODE_WEIGHTED_AVERAGE: w = max(1 - weight_falloff * d, 0)^2
     float fog_density;
     float fog_color[3];
     uint32_t color_count;

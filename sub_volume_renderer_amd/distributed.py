@@ -98,17 +98,29 @@ class TiledFrame:
         import torch.distributed as dist
 
         lib, handle = N.lib(), volume._rings.handle
+        dev = torch.device("cuda", volume._rings.device)
+
+        def all_ok(ok: int) -> bool:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        # the id: rank 0 makes it; a rank-0 failure travels as None, so that no rank enters ncclCommInitRank alone
+        buf = C.create_string_buffer(128)
+        made = self.rank != 0 or lib.svr_comm_unique_id(C.cast(buf, C.POINTER(C.c_char * 128)).contents) == 0
+        box = [buf.raw if (self.rank == 0 and made) else None]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return False
+        ident = (C.c_char * 128).from_buffer_copy(box[0])
+        joined = lib.svr_comm_init(handle, ident, self.rank, self.world) == 0
+        if not all_ok(int(joined)):                        # some rank has no communicator: nobody starts a send / recv on it
+            if joined:
+                lib.svr_comm_destroy(handle)
+            return False
         ok = 1
         try:
-            buf = C.create_string_buffer(128)
-            if self.rank == 0:
-                N.check(lib.svr_comm_unique_id(C.cast(buf, C.POINTER(C.c_char * 128)).contents), "svr_comm_unique_id")
-            box = [buf.raw if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ident = (C.c_char * 128).from_buffer_copy(box[0])
-            N.check(lib.svr_comm_init(handle, ident, self.rank, self.world), "svr_comm_init")
             self._comm_volume = volume
-            dev = torch.device("cuda", volume._rings.device)
             probe = torch.full((self.rows_per_rank, self.cols_per_rank, 1), float(self.rank + 1), device=dev)
             got = self.gather(probe, dst=0, volume=volume)
             torch.cuda.synchronize(dev)
@@ -120,9 +132,7 @@ class TiledFrame:
                         ok = 0
         except Exception:  # noqa: BLE001 - any failure here means "use the torch transport"
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", volume._rings.device))
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        if not all_ok(ok):
             self._comm_volume = None
             return False
         return True

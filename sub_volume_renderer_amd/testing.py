@@ -72,7 +72,7 @@ def build(spec: SceneSpec, device: int | None = None) -> BuiltScene:
     """Product side: a ``SubVolume`` with the spec's loads applied (needs the GPU)."""
     # keys that are constructor arguments in the reference vs properties inherited from pygfx's Material /
     # added here (set after construction, as a caller of the reference would)
-    later = ("clipping_planes", "clipping_mode", "render_mode")
+    later = ("clipping_planes", "clipping_mode", "render_mode", "weight_falloff")
     material = SubVolumeMaterial(**{k: v for k, v in spec.material.items() if k not in later})
     for k in later:
         if k in spec.material:

@@ -92,6 +92,26 @@ def test_material_validation():
     assert int(m._color_count) == 1 and m.colors[0][3] == 1.0
 
 
+def test_render_modes_are_a_material_switch():
+    """FUTURE.md:111-120: "different materials that could indicate which rendering mode we are in"."""
+    m = SubVolumeMaterial(0.5)
+    assert m.render_mode == "lmip" and m.weight_falloff == 0.5
+    for mode in ("mip", "weighted_average", "LMIP"):
+        m.render_mode = mode
+        assert m.render_mode == mode.lower()
+    with pytest.raises(ValueError):
+        m.render_mode = "fading"
+    assert m.lmip_uniforms() == (0.5, 0.5, 10)              # the lmip_* properties survive mode changes
+    v = m._version
+    m.weight_falloff = 2
+    assert m.weight_falloff == 2.0 and m._version > v
+    for bad in (-0.1, float("inf"), float("nan")):
+        with pytest.raises(ValueError):
+            m.weight_falloff = bad
+    # the C struct carries both (ABI 6)
+    assert {"render_mode", "weight_falloff"} <= {name for name, _ in _native.Material._fields_}
+
+
 # ---- SubVolume (_wobject.py:20-208) ---------------------------------------------
 def pairs(n=3, base=32):
     out = []

@@ -1,5 +1,5 @@
 """GPU: the material features beside the plain LMIP uniforms — clipping planes (fs_main.wgsl:8), the MIP
-render mode (FUTURE.md:97-120) — and uint16 ring storage, each against the CPU oracle on identical inputs."""
+and weighted-average render modes (FUTURE.md:97-120) — and uint16 ring storage, each against the CPU oracle on identical inputs."""
 import numpy as np
 import pytest
 
@@ -136,3 +136,39 @@ def test_volume_without_segmentation_renders_every_hit_with_label_zero(inside):
         scene.volume.wrapping_buffers[0]._upload(__import__("sub_volume_renderer_amd").Roi((0, 0, 0), (8, 8, 16)),
                                                  np.zeros((8, 8, 16), np.uint8), np.zeros((8, 8, 16), np.uint32))
     torch.cuda.synchronize()
+
+
+# ---- weighted-average mode (SVR_MODE_WEIGHTED_AVERAGE, include/svr.h) ---------------------------------------------
+@pytest.mark.parametrize("falloff", [0.0, 0.5, 4.0])
+@pytest.mark.parametrize("storage", ["native", "float32"])
+@pytest.mark.parametrize("inside", [False, True], ids=["K1", "K2"])
+def test_weighted_average_mode_matches_oracle(inside, storage, falloff):
+    spec = testing.synthetic_spec(64, 160, 96, inside=inside)
+    spec.ring_storage = storage
+    spec.material.update(render_mode="weighted_average", weight_falloff=falloff)
+    scene = testing.build(spec)
+    assert scene.volume.material.render_mode == "weighted_average" and scene.volume.material.weight_falloff == falloff
+    _, ref, rep = check(scene)
+    assert rep["n_hit"] > 1000
+    # the mode is a material switch: back to LMIP on the same volume, with the lmip_* properties as they were
+    scene.volume.material.render_mode = "lmip"
+    scene.spec.material.update(render_mode="lmip")
+    _, ref2, rep2 = check(scene)
+    assert not np.array_equal(ref2.rgba, ref.rgba)
+
+
+def test_weighted_average_regions_label_less_volume_and_uint16():
+    from sub_volume_renderer_amd import FrameRegion, synth
+
+    pairs = []
+    for k in range(3):
+        d, _ = synth.volume(64, k)
+        pairs.append((d.astype(np.uint16) * 257, None))
+    spec = testing.synthetic_spec(64, 150, 90, pairs=pairs)
+    spec.material.update(render_mode="weighted_average", weight_falloff=1.0, clim=(0.0, 65535.0))
+    scene = testing.build(spec)
+    assert scene.volume._rings.density_storage == "uint16"
+    res, ref, rep = check(scene)
+    assert np.all(ref.label == 0)
+    for region in (FrameRegion.tile(13, 7, 100, 50), FrameRegion.stripes(150, 90, 1, 3, 8)):
+        check(scene, region=region, want_hits=False)

@@ -209,3 +209,86 @@ def test_mip_mode_through_the_lmip_machine_equals_mip_stated_directly(name):
     full = dict(spec.material, render_mode="lmip", lmip_threshold=float("inf"))
     spec.material = full
     np.testing.assert_array_equal(a.steps, lmip.render_spec(spec, nthreads=2).steps)      # MIP walks the whole ray
+
+
+# ---- weighted-average render mode (named in FUTURE.md:97-109, defined by this project: include/svr.h) ----------------
+@pytest.mark.parametrize("falloff", [0.0, 0.5, 3.0])
+@pytest.mark.parametrize("name", ["k1", "k2"])
+def test_weighted_average_two_restatements_agree(name, falloff):
+    spec = make_golden.specs()[name]
+    spec.material = dict(spec.material, render_mode="weighted_average", weight_falloff=falloff)
+    a = lmip.render_spec(spec, nthreads=2)
+    b = lmip_numpy.render_spec(spec)
+    np.testing.assert_array_equal(a.flags, b["flags"])
+    np.testing.assert_array_equal(a.steps, b["steps"])
+    np.testing.assert_array_equal(a.label, b["label"])
+    np.testing.assert_allclose(a.rgba, b["rgba"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a.depth, b["depth"], rtol=0, atol=2e-6)
+    assert (a.flags == 2).sum() > 500
+    plain = make_golden.specs()[name]
+    plain.material = dict(plain.material, lmip_threshold=float("inf"))            # LMIP that never triggers: the whole ray
+    whole = lmip.render_spec(plain, nthreads=2)
+    if falloff <= 0.5:                     # range 1 / falloff >= 2 volume edges: longer than any ray, nothing is cut
+        np.testing.assert_array_equal(a.steps, whole.steps)
+    else:                                  # range 1/3 of an edge: long rays stop early
+        assert np.all(a.steps <= whole.steps) and (a.steps < whole.steps).sum() > 500
+
+
+def test_weighted_average_known_answers():
+    """Uniform volume of ones: sum(w * 1) == sum(w) bit for bit, so the mean is exactly 1 whatever the weights;
+    the largest contribution is the first sample's (w = 1, later ones weigh less) -> offset 0 -> no fog:
+    the same pure green as the LMIP known answer.  All zeros: nothing contributes -> a miss, black and opaque.
+    Range shorter than one step: exactly one sample per ray."""
+    spec = _uniform_scene(1.0, 0.5)
+    spec.material.update(render_mode="weighted_average", weight_falloff=0.5)
+    r = lmip.render_spec(spec)
+    hit = r.flags == 2
+    assert hit.sum() > 0 and (r.flags == 1).sum() < 0.05 * hit.sum()
+    want = np.tile(np.array([0, 1, 0, 0.9], np.float32), (hit.sum(), 1))
+    # rays entering through a high face take their first sample outside every ROI (value 0): the mean is then a
+    # little below 1 and the strongest sample is the second one
+    exact = np.all(np.abs(r.rgba[hit] - want) <= 1e-6, axis=1)
+    assert exact.mean() > 0.5
+    assert np.all(r.rgba[hit][:, 1] <= 1.0 + 1e-6) and np.all(r.rgba[hit][:, [0, 2]] <= 5e-3)      # never brighter than the data
+    assert np.all(r.label[hit] == 2)
+
+    zero = _uniform_scene(0.0, 0.5)
+    zero.material.update(render_mode="weighted_average")
+    z = lmip.render_spec(zero)
+    frag = z.flags != 0
+    assert frag.sum() > 0 and (z.flags == 2).sum() == 0
+    assert np.all(z.rgba[frag] == np.array([0, 0, 0, 1], np.float32))
+
+    spec.material.update(weight_falloff=1.0e4)            # range 1e-4 of an edge: the second sample already weighs nothing
+    one = lmip.render_spec(spec)
+    assert np.all(one.steps[one.flags != 0] == 1)
+
+
+def test_weighted_average_prefers_near_structures():
+    """Two bright slabs of equal value along z, camera on the -z side... the pixel is shown at the slab nearer to
+    the ray's entry (larger weight), and a larger fall-off moves the mean towards the near part of the ray."""
+    n = 32
+    d = np.zeros((n, n, n), np.float32)
+    d[4:8] = 1.0                                           # z in [4, 8)
+    d[24:28] = 1.0                                         # z in [24, 28)
+    seg = np.zeros(d.shape, np.uint32)
+    seg[4:8], seg[24:28] = 1, 2
+    spec = testing.synthetic_spec(n, 48, 36, pairs=[(d, seg)], chunk_shapes=[(8, 8, 8)], ring_shapes=[(4, 4, 4)])
+    spec.centers = [((15.5, 15.5, 15.5), [(n, n, n)])]
+    spec.material = dict(lmip_threshold=0.5, fog_density=0.0, colors=[(0.0, 0.0, 1.0)], clim=(0.0, 1.0),
+                         render_mode="weighted_average", weight_falloff=0.5)
+    spec.cam_position, spec.cam_target = (15.5, 15.5, -60.0), (15.5, 15.5, 15.5)
+    near_first = lmip.render_spec(spec)
+    hit = near_first.flags == 2
+    centre = (slice(14, 22), slice(20, 28))                # rays through both slabs
+    assert np.all(near_first.label[centre] == 1)
+    spec.cam_position = (15.5, 15.5, 91.0)
+    far_first = lmip.render_spec(spec)
+    assert np.all(far_first.label[centre] == 2)
+    # grey value = the mean itself (saturation 0, clim 0..1, no fog; "linear" so that no transfer curve is applied)
+    spec.colorspace = "linear"
+    lo = lmip.render_spec(spec).rgba[centre][..., 0]
+    spec.material.update(weight_falloff=1.0)
+    hi = lmip.render_spec(spec).rgba[centre][..., 0]
+    assert np.all((lo > 0.05) & (lo < 0.6))                # 8 of ~32 voxels along the ray are bright
+    assert hit.sum() > 100 and not np.allclose(lo, hi)

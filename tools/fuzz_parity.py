@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the HIP march against the CPU oracle: random volumes (1-4 LODs, random chunk
 and ring shapes, anisotropic, u8 / u16 / f32 rings, with or without segmentation), ring windows, cameras (outside /
-inside / grazing), materials (LMIP and MIP, clipping planes), frame sizes, frame regions and kernel variants
+inside / grazing), materials (LMIP, MIP and weighted average, clipping planes), frame sizes, frame regions and kernel variants
 (empty-space skipping on and off, bricks always / never / by probe, tile shapes, placements).  Integer planes must be identical, float planes within 1e-4.
 usage: fuzz_parity.py [cases] [first_seed] [brick]      (prints one line per failing case, then a summary)"""
 import os
@@ -122,7 +122,12 @@ def random_spec(seed, brick=False):
     elif r < 0.35:
         world = int(rng.integers(2, 5))
         region = FrameRegion.stripes(W, H, int(rng.integers(0, world)), world, int(rng.choice([1, 3, 8, 16])))
-    return spec, region, int(rng.choice(BRICK_VARIANTS if brick else VARIANTS))
+    variant = int(rng.choice(BRICK_VARIANTS if brick else VARIANTS))
+    last = rng.random(2)                                      # drawn after everything else (earlier seeds keep their scene)
+    if last[0] < 0.08 and spec.material.get("render_mode", "lmip") == "lmip":
+        spec.material["render_mode"] = "weighted_average"
+        spec.material["weight_falloff"] = float(rng.choice([0.0, 0.5, last[1] * 6.0]))
+    return spec, region, variant
 
 
 def main():
