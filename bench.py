@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed frames (default 20; C4: 240)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prime-s", type=float, default=0.3, help="seconds of untimed frames during setup, before the warm-up "
+                    "frames (the first ~50 ms of frames after an idle GPU run 3-4 %% slower: clocks ramping)")
     ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
     ap.add_argument("--volume-n", dest="n", type=int, default=None, help="volume edge (C2 1024, C5 2048, C4 4096)")
     ap.add_argument("--width", type=int, default=1920)
@@ -271,7 +273,7 @@ def main():
     # carries render -> gather -> un-tile of its frames, so frame k's collective and its tail of long rays overlap
     # frame k+1's march.
     class FrameLoop:
-        def __init__(self, F):
+        def __init__(self, F, prime_s=0.0):
             self.F = F
             self.outs = []
             for _ in range(F):
@@ -281,6 +283,19 @@ def main():
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [torch.cuda.current_stream(dev)]
             self.k = 0
             self.last = None
+            # per-stream resources of the library (placement table + its pinned staging buffer, render marks) are
+            # created at a stream's first render: do that here, during setup (a short warm-up never reaches the 4th
+            # stream); `prime_s` seconds of untimed frames on top let the GPU's clocks ramp up before the W warm-up frames
+            set_mode(True)
+            t_end = time.perf_counter() + prime_s
+            i = 0
+            while i < 2 * F or time.perf_counter() < t_end:
+                with torch.cuda.stream(self.streams[i % F]):
+                    vol.render(cam, W, H, region=region, out=self.outs[i % F])
+                i += 1
+                if i % 16 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
         def planes_of(self, res):
             return (res.rgba, res.depth, res.label) if want_all else res.rgba
@@ -345,7 +360,7 @@ def main():
         for mode in modes:
             set_mode(mode == "full")
             counts[mode] = instrumented(cam)
-        loop = FrameLoop(max(1, args.in_flight))
+        loop = FrameLoop(max(1, args.in_flight), prime_s=args.prime_s)
         seq = loop if loop.F == 1 else FrameLoop(1)
         dts = {}
         for mode in modes:
@@ -409,6 +424,7 @@ def main():
                                    f"{'rgba+depth+label' if want_all else 'rgba'} via {transport}",
                     "kernel_variant": args.variant,
                     "frames_in_flight": loop.F,
+                    "setup_prime_s": args.prime_s,
                     "placement": "64x64-pixel chunks in raster order (svr_set_variant policy 7) for the pipelined loop; "
                                  "cost-sorted per camera (policy 0, default) for `sequential` and `roofline`"
                                  if (loop.F > 1 and not (args.variant >> 13) & 7) else "as --variant says (0: cost-sorted per camera)",

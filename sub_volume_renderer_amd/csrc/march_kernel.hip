@@ -718,6 +718,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // (P.lmip_threshold_raw, one past the largest value when none can reach it), f32 texels against the threshold itself
     texel_t thr_raw;
     if constexpr (ESH != 2) thr_raw = P.lmip_threshold_raw; else thr_raw = P.lmip_threshold;
+    const bool mip_like = (P.skip_flags & 2) != 0;           // wave-uniform
     auto lmip_batch = [&](const texel_t (&sv)[U], int nb, bool live, bool tail) {
         // u8: 0 is neutral (a live lane always has one real sample); f32: -1 < every |s|
         texel_t m;
@@ -725,7 +726,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const texel_t neutral = m;
 #pragma unroll
         for (int u = 0; u < U; ++u) m = texel_max(m, (tail && (nb + u) >= nsteps) ? neutral : texel_abs(sv[u]));
-        const bool need = live && (found || m >= thr_raw);
+        // a lane that follows a maximum needs the batch too — unless the machine can never stop (MIP: no fall-off, no
+        // sample limit; host: skip_flags bit 1) and nothing in the batch beats its maximum (raycast.wgsl:50 is a strict >)
+        bool need;
+        if (mip_like) need = live && (found ? texel_value(m) > local_max : m >= thr_raw);
+        else need = live && (found || m >= thr_raw);
         if (__builtin_amdgcn_ballot_w64(need) != 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -972,9 +977,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const texel_t m = texel_max(texel_max(texel_abs(v[0]), texel_abs(v[1])), texel_max(texel_abs(v[2]), texel_abs(v[3])));
                         // a lane that tracks a maximum, moves too fast for the test, or passes a block that may hold a
                         // significant value vetoes the skip
+                        // (MIP: a lane that follows a maximum only vetoes for a block that may beat it)
                         const bool occupied = live && !found && (!slow || m >= thr_raw);
+                        const bool following = live && found && (!mip_like || !slow || texel_value(m) > local_max);
                         const unsigned long long occ_mask = __builtin_amdgcn_ballot_w64(occupied);
-                        if (occ_mask != 0 || __builtin_amdgcn_ballot_w64(live && found) != 0) {
+                        if (occ_mask != 0 || __builtin_amdgcn_ballot_w64(following) != 0) {
                             vetoed = true;
                             tracking_only = occ_mask == 0;         // every vetoing lane is already following a maximum
                             break;
@@ -990,7 +997,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         // long enough for that, with plain gathers, and come back to skipping)
                         int cap = 4 * sb;
                         if (brick_mode && L.slab > 0) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
-                        if (tracking_only && (P.skip_flags & 1)) cap = min(cap, 2);
+                        if (tracking_only && (P.skip_flags & 1) && !mip_like) cap = min(cap, 2);     // (MIP lanes follow their maximum to the ray's end)
                         if (run > cap) { held = run - cap; run = cap; }
                     }
                 }

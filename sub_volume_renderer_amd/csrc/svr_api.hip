@@ -970,11 +970,15 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     // skip only when some texel value can reach the threshold and not every one does: threshold = +inf (or NaN)
     // is the "full" march, whose point is the traversal itself; variant bit 3 switches skipping off (A/B)
-    const bool skip = c->cells_dil_all && !(c->variant & 8) && P.lmip_threshold_raw > 0u &&
+    // A state machine that can never stop (no fall-off, no sample limit: MIP, _material.py lmip_uniforms) is the running
+    // maximum of the ray; a lane that follows one can then pass every block that cannot beat it, like an empty one.
+    const bool mip_like = m.lmip_fall_off == 0.0f && m.lmip_max_samples == INT32_MAX;
+    const bool skip = c->cells_dil_all && !(c->variant & 8) &&
+                      (mip_like || (P.lmip_threshold_raw > 0u &&
                       (c->density_storage == SVR_F32 ? (m.lmip_threshold > 0.0f && m.lmip_threshold < INFINITY)
-                                                     : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u));
+                                                     : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u))));
     static const int skip_flags_env = getenv("SVR_SKIP_FLAGS") ? atoi(getenv("SVR_SKIP_FLAGS")) : 1;      // A/B measurements
-    P.skip_flags = skip_flags_env;
+    P.skip_flags = (skip_flags_env & 1) | (mip_like ? 2 : 0);
     P.cells_all = skip ? c->cells_dil_all : nullptr;
     P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;
     if (!brick_bytes_env && !skip) {

@@ -89,7 +89,8 @@ struct MarchParams {
     int32_t brick;                 // 0 never / 1 per-wave probe / 2 always: LDS bricks (u8 rings only)
     int32_t brick_lod_mask;        // LODs allowed to use bricks (bit l)
     int32_t slab_long;             // 1: brick slabs start at twice their plain length
-    int32_t skip_flags;            // empty-space skipping policy bits (1: short march while lanes only follow a maximum)
+    int32_t skip_flags;            // empty-space skipping policy bits (1: short march while lanes only follow a maximum; 2: MIP-like
+                                   // uniforms — the machine never stops — so a lane that follows a maximum passes blocks that cannot beat it)
     int32_t brick_bytes;           // LDS bytes per wave for brick staging (also what caps the waves per CU: 160 KiB / it)
     int32_t brick_pow2;            // A/B: round the brick row pitch up to a power of two (the round-1 layout)
     int32_t block_waves_log2;      // span kernel: block = (1 << this)^2 wave tiles (0: one wave per block)

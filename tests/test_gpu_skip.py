@@ -13,11 +13,11 @@ from test_gpu_render import check
 pytestmark = pytest.mark.gpu
 
 
-def _sparse_pairs(n, seed, value=200, count=40, dtype=np.uint8):
+def _sparse_pairs(n, seed, value=200, count=40, dtype=np.uint8, noise=12):
     """Three LODs (2x mean / max pooled) of a dark volume with a few isolated bright voxels, many of them on the
     corners, edges and faces of the 8^3 macro cells."""
     rng = np.random.default_rng(seed)
-    d0 = rng.integers(0, 12, (n, n, n)).astype(dtype)
+    d0 = rng.integers(0, noise, (n, n, n)).astype(dtype)
     l0 = np.zeros((n, n, n), np.uint32)
     for k in range(count):
         p = rng.integers(1, n - 2, 3)
@@ -92,6 +92,40 @@ def test_skip_on_equals_skip_off_and_really_skips(storage, dtype, scale):
     N.check(N.lib().svr_debug_counters(vol._rings.handle, census, 1), "svr_debug_counters")
     assert skipped > 1000 and census[7] == 0                # the default took skips, the A/B run none
     check(scene, want_hits=False)                           # and both are the oracle's frame
+
+
+@pytest.mark.parametrize("cam", ["K1", "K2", "diag"])
+@pytest.mark.parametrize("storage,dtype,scale", [("native", np.uint8, 1), ("float32", np.uint8, 1), ("native", np.uint16, 257)])
+def test_mip_mode_skips_what_cannot_beat_the_running_maximum(storage, dtype, scale, cam):
+    """MIP (no fall-off, no sample limit): once a ray holds a maximum, blocks whose maximum does not exceed it are
+    passed like empty ones (raycast.wgsl:50 replaces only on a strict >).  Bright blobs of EQUAL value behind one
+    another: the first one must stay the hit."""
+    import ctypes as C
+
+    import torch
+
+    pairs = [(d.astype(dtype) * scale, l) for d, l in _sparse_pairs(128, 3, count=16, noise=1)]     # background 0: only the blobs beat a maximum
+    spec = _scene(128, pairs, 150.0 * scale, cam, storage)
+    spec.material.update(clim=(0.0, 255.0 * scale), render_mode="mip")
+    scene = testing.build(spec)
+    vol = scene.volume
+    on = vol.render(scene.camera, spec.width, spec.height, count_steps=True)
+    torch.cuda.synchronize()
+    on = {k: getattr(on, k).clone() for k in ("rgba", "depth", "label", "flags", "steps")}
+    census = (C.c_uint32 * 8)()
+    N.check(N.lib().svr_debug_counters(vol._rings.handle, census, 1), "svr_debug_counters")
+    skipped = census[7]
+    N.check(N.lib().svr_set_variant(vol._rings.handle, 8), "svr_set_variant")      # bit 3: no skipping
+    off = vol.render(scene.camera, spec.width, spec.height, count_steps=True)
+    torch.cuda.synchronize()
+    for k, v in on.items():
+        assert torch.equal(getattr(off, k), v), k
+    assert skipped > 50
+    N.check(N.lib().svr_set_variant(vol._rings.handle, 0), "svr_set_variant")
+    _, ref, rep = check(scene)
+    assert rep["n_miss"] == 0                                # every fragment yields its maximum
+    if cam != "K2":                                          # (the inside camera sees few of the 16 blobs)
+        assert len(np.unique(ref.label[ref.flags == 2])) >= 3
 
 
 def test_stale_maxima_after_window_moves_stay_conservative():

@@ -8,7 +8,7 @@ TAG=${1:-r02}; ROUND=${2:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --modes full --no-cpu-baseline --in-flight 1 --repeats 1"   # one frame at a time: per-dispatch durations stay comparable with roofline.kernel_ms
+ARGS="--steps 10 --warmup 2 --modes full --no-cpu-baseline --in-flight 1 --repeats 1 --prime-s 0"   # one frame at a time: per-dispatch durations stay comparable with roofline.kernel_ms
 CMD="python3 $ROOT/bench.py $ARGS"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUFFER_WAVEFRONTS_sum" \
