@@ -57,4 +57,4 @@ for camname in ("K1", "K2"):
             torch.cuda.synchronize()
             c = census(vol)
             print(f"{camname} {mode} variant {variant}: {time_ms(vol, cam, W, H):.3f} ms; steps {int(r.steps.to(torch.int64).sum())/1e6:.1f} M; "
-                  f"batches skipped {c[7]}, brick {c[2]}, direct {c[1]}, general {c[0]}", flush=True)
+                  f"batches skipped {c[7]}, brick {c[2]}, direct {c[1]}, general {c[0]}; census {c}", flush=True)
