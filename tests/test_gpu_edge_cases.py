@@ -4,7 +4,6 @@ degenerate material values (the integer pre-check of the byte rings must agree w
 import numpy as np
 import pytest
 
-from oracle import lmip
 from sub_volume_renderer_amd import _native as N, testing
 
 from test_gpu_render import check

@@ -78,8 +78,6 @@ def test_c2_ring_addressing_property(c2):
 
 
 def test_c2_tiles_stripes_and_variants_equal_full_frame(c2):
-    import ctypes as C
-
     import torch
 
     from sub_volume_renderer_amd import _native as N

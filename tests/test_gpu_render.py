@@ -217,8 +217,6 @@ def test_async_streaming_protocol_never_tears():
     ROI), whatever the timing; the final state equals the synchronous result."""
     import torch
 
-    from oracle import ring_oracle as R
-
     spec = testing.synthetic_spec(64, 96, 64, inside=True)
     scene = testing.build(spec)
     vol = scene.volume

@@ -285,9 +285,6 @@ def test_rings_beyond_the_span_kernels_24_bit_row_index_render_exactly():
     arithmetic cannot address it, so the draw takes the straightforward kernel — same pixels as the oracle."""
     import torch
 
-    from sub_volume_renderer_amd import SubVolume, SubVolumeMaterial
-    from sub_volume_renderer_amd._transform import PerspectiveCamera
-
     n = (48, 40, 64)                                          # the data is small; the RING is huge
     rng = np.random.default_rng(4)
     data = rng.integers(0, 255, n, dtype=np.uint8)

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from sub_volume_renderer_amd import Roi, _native as N, synth, testing  # noqa: E402
+from sub_volume_renderer_amd import _native as N, synth, testing  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 W, H = 1920, 1080
