@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""MIP mode: batches skipped / marched (census of the instrumented kernel) and kernel time with and without skipping."""
+"""MIP mode (and the weighted-average mode, which has its own kernel): batches skipped / marched (census of the instrumented kernel) and kernel time with and without skipping."""
 import ctypes as C
 import os
 import sys
@@ -47,9 +47,9 @@ pairs = [synth.volume(n, k, 4096, xp=torch, device=dev, slab=16) for k in range(
 for camname in ("K1", "K2"):
     scene = testing.build(bench.config2_spec(n, W, H, camname, pairs))
     vol, cam = scene.volume, scene.camera
-    for mode in ("lmip", "mip"):
+    for mode in ("lmip", "mip", "weighted_average"):
         vol.material.render_mode = mode
-        for variant in (0, 8):
+        for variant in ((0, 8) if mode != "weighted_average" else (0,)):
             N.check(N.lib().svr_set_variant(vol._rings.handle, variant), "variant")
             census(vol)
             r = vol.render(cam, W, H, count_steps=True)
