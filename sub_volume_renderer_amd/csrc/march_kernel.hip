@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void march_simple(const MarchParams P) {
 // distance, fs_main.wgsl:82); the pixel shows sum(w s) / sum(w) at the sample with the largest w |s|.
 // Same ray, same sample positions and the same LOD fall-through as raycast.wgsl:29-32; sums in sample order, so
 // the CPU twin (oracle/lmip_oracle.c raycast_weighted_average) reproduces every bit.  One texel fetch per
-// step from global memory, like march_simple.
+// step from global memory, like march_simple: the fallback where the span march (which carries this mode as a second
+// batch reducer, see lmip_batch) cannot address the rings.
 // ---------------------------------------------------------------------------
 template <int NL, bool COUNT>
 __global__ __launch_bounds__(256) void march_wavg(const MarchParams P) {
@@ -586,7 +587,7 @@ struct LodEvents {
 
 // LDS bricks: one private region of MarchParams::brick_bytes per wave (dynamic LDS, see launch_nl)
 
-template <int NL, int U, bool COUNT, int ESH, bool BIG>
+template <int NL, int U, bool COUNT, int ESH, bool BIG, bool WAVG = false>
 __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // dynamic LDS: kBrickBytes per wave of the block (u8 rings), see launch_nl
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
@@ -719,7 +720,33 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     texel_t thr_raw;
     if constexpr (ESH != 2) thr_raw = P.lmip_threshold_raw; else thr_raw = P.lmip_threshold;
     const bool mip_like = (P.skip_flags & 2) != 0;           // wave-uniform
+    // SVR_MODE_WEIGHTED_AVERAGE (include/svr.h) is another reducer over the same batches: local_max holds the largest
+    // contribution so far, samp the weighted sum, den the sum of weights; the lane is finished at its first weightless sample
+    // (its own instantiations, WAVG: the LMIP kernels do not carry a single instruction of it)
+    float den = 0.f;
     auto lmip_batch = [&](const texel_t (&sv)[U], int nb, bool live, bool tail) {
+        if constexpr (WAVG) {
+            const float steplen = sqrtf((Rtx * Rtx + Rty * Rty) + Rtz * Rtz);
+            const float k = fresh_params(P)->weight_falloff;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool act = live && !finished && (!tail || (nb + u) < nsteps);
+                const float tw = 1.0f - k * ((float)(nb + u) * steplen);
+                const bool go = act && tw > 0.0f;
+                finished = finished || (act && !go);
+                if (COUNT) steps += go ? 1u : 0u;
+                const float val = texel_value(sv[u]);
+                const float w = tw * tw;
+                const float contribution = w * fabsf(val);
+                const float num1 = samp + w * val, den1 = den + w;
+                samp = go ? num1 : samp;
+                den = go ? den1 : den;
+                const bool take = go && contribution > local_max;
+                local_max = take ? contribution : local_max;
+                hit_i = take ? (nb + u) : hit_i;
+            }
+            return;
+        }
         // u8: 0 is neutral (a live lane always has one real sample); f32: -1 < every |s|
         texel_t m;
         if constexpr (ESH != 2) m = 0u; else m = -1.0f;
@@ -1152,6 +1179,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     }
     Hit h;
     h.found = found; h.sample = samp; h.steps = steps;
+    if constexpr (WAVG) { h.found = local_max > 0.0f; h.sample = h.found ? samp / den : 0.0f; }
     const float hit_f = (float)hit_i;
     h.offset = { hit_f * Rtx, hit_f * Rty, hit_f * Rtz };                    // raycast.wgsl:30
     h.coord = { Rsx + h.offset.x, Rsy + h.offset.y, Rsz + h.offset.z };   // :31
@@ -1182,7 +1210,8 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
     const int nblocks = p.tiles_x * p.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     const bool simple = kind == 1 || !p.span_ok;                 // rings the 32-bit / 24-bit addressing of the span kernel cannot reach
-    if (p.render_mode == SVR_MODE_WEIGHTED_AVERAGE) {
+    const bool wavg = p.render_mode == SVR_MODE_WEIGHTED_AVERAGE;
+    if (wavg && (simple || p.per_lod_rsrc)) {
         if (p.steps) hipLaunchKernelGGL((march_wavg<NL, true>), dim3(nblocks), dim3(256), 0, stream, p);
         else         hipLaunchKernelGGL((march_wavg<NL, false>), dim3(nblocks), dim3(256), 0, stream, p);
     } else if (simple) {
@@ -1201,9 +1230,20 @@ hipError_t launch_nl(const MarchParams& p, int kind, hipStream_t stream) {
             else         hipLaunchKernelGGL((march_span<NL, 8, false, ESH_, false>), dim3(nblocks), dim3(threads), lds, stream, p); \
         }                                                                                                                  \
     } while (0)
-        if (p.density_esh == 0) SVR_LAUNCH_SPAN(0);
+#define SVR_LAUNCH_WAVG(ESH_)                                                                                              \
+    do {                                                                                                                   \
+        if (p.steps) hipLaunchKernelGGL((march_span<NL, 8, true, ESH_, false, true>), dim3(nblocks), dim3(threads), lds, stream, p);   \
+        else         hipLaunchKernelGGL((march_span<NL, 8, false, ESH_, false, true>), dim3(nblocks), dim3(threads), lds, stream, p);  \
+    } while (0)
+        if (wavg) {
+            if (p.density_esh == 0) SVR_LAUNCH_WAVG(0);
+            else if (p.density_esh == 1) SVR_LAUNCH_WAVG(1);
+            else SVR_LAUNCH_WAVG(2);
+        }
+        else if (p.density_esh == 0) SVR_LAUNCH_SPAN(0);
         else if (p.density_esh == 1) SVR_LAUNCH_SPAN(1);
         else SVR_LAUNCH_SPAN(2);
+#undef SVR_LAUNCH_WAVG
 #undef SVR_LAUNCH_SPAN
     }
     return hipGetLastError();

@@ -877,8 +877,11 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     // wave tile width (0 = default 8x8), bit 8 = disable the LDS brick path
     int lw = ((c->variant >> 4) & 15) ? ((c->variant >> 4) & 15) - 1 : 3;
     if (lw > 6) lw = 6;
-    const bool wavg = m.render_mode == SVR_MODE_WEIGHTED_AVERAGE;  // its own kernel, laid out like the simple one
-    if ((c->variant & 3) == 1 || wavg) lw = 3;                // the simple kernel is 8x8 only
+    // the weighted-average mode rides the span march (another reducer over the same batches); rings the span march
+    // cannot address, and variant 1, take march_wavg, which is laid out like the simple kernel
+    const bool wavg_simple = m.render_mode == SVR_MODE_WEIGHTED_AVERAGE &&
+                             ((c->variant & 3) == 1 || !span_addressable(c) || c->density_all_bytes >= ((size_t)1 << 32));
+    if ((c->variant & 3) == 1 || wavg_simple) lw = 3;         // the simple kernels are 8x8 only
     P.tile_log2w = lw;
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
@@ -904,7 +907,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     // kernel kind 0: span march, one wave per block; 2: span march, 2 x 2 waves per block; 1: simple (2 x 2)
     // (rings of 4 GiB or more fall back to the simple kernel's 64-bit addressing, see launch_nl)
-    P.block_waves_log2 = ((c->variant & 3) == 0 && span_addressable(c) && !wavg) ? 0 : 1;
+    P.block_waves_log2 = ((c->variant & 3) == 0 && span_addressable(c) && !wavg_simple) ? 0 : 1;
     const int bw = (1 << P.block_waves_log2) << lw, bh = (1 << P.block_waves_log2) * (64 >> lw);
     P.tiles_x = (fr->out_w + bw - 1) / bw; P.tiles_y = (fr->out_h + bh - 1) / bh;
     {   // variant bits 13-15: block -> tile policy (0 default = 64x64-pixel chunks dealt to the XCDs, 1 contiguous, 2.. other chunks)
@@ -973,7 +976,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     // A state machine that can never stop (no fall-off, no sample limit: MIP, _material.py lmip_uniforms) is the running
     // maximum of the ray; a lane that follows one can then pass every block that cannot beat it, like an empty one.
     const bool mip_like = m.lmip_fall_off == 0.0f && m.lmip_max_samples == INT32_MAX;
-    const bool skip = c->cells_dil_all && !(c->variant & 8) &&
+    const bool skip = c->cells_dil_all && !(c->variant & 8) && m.render_mode == SVR_MODE_LMIP &&       // (a mean needs every sample)
                       (mip_like || (P.lmip_threshold_raw > 0u &&
                       (c->density_storage == SVR_F32 ? (m.lmip_threshold > 0.0f && m.lmip_threshold < INFINITY)
                                                      : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u))));

@@ -172,3 +172,9 @@ def test_weighted_average_regions_label_less_volume_and_uint16():
     assert np.all(ref.label == 0)
     for region in (FrameRegion.tile(13, 7, 100, 50), FrameRegion.stripes(150, 90, 1, 3, 8)):
         check(scene, region=region, want_hits=False)
+    # the one-fetch-per-step kernel (march_wavg: the fallback for rings the span march cannot address) is the same frame
+    from sub_volume_renderer_amd import _native as N
+
+    N.check(N.lib().svr_set_variant(scene.volume.prepare(), 1), "svr_set_variant")
+    check(scene)
+    check(scene, region=FrameRegion.stripes(150, 90, 2, 3, 8), want_hits=False)
