@@ -952,7 +952,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         {   // brick slabs (u8 rings): about 12 ring voxels of travel per slab (coarser LODs advance less per
             // iteration); rows in 16-byte groups, indices below 2^15 for the packed (y, z) brick address
             const float smax = fmaxf(Q.scale[0], fmaxf(Q.scale[1], Q.scale[2]));
-            const int slab = smax > 0.75f ? 16 : (smax > 0.375f ? 32 : 64);
+            static const int slab_shift = getenv("SVR_SLAB_SHIFT") ? atoi(getenv("SVR_SLAB_SHIFT")) : 0;     // A/B measurements
+            const int slab = std::max(8, (smax > 0.75f ? 16 : (smax > 0.375f ? 32 : 64)) >> slab_shift);
             // (ring rows must be whole 16-byte groups: 16 / 8 / 4 voxels for u8 / u16 / f32 rings)
             bool ok = ((Q.ring[0] * des) & 15u) == 0u && (brick_mask >> l & 1);
             for (int a = 0; a < 3; ++a) ok = ok && (long long)Q.off[a] + (long long)Q.shape[a] < 32768;
