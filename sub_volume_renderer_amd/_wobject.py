@@ -65,6 +65,15 @@ class RenderResult:
         return self.label.cpu().numpy().view(np.uint32)
 
 
+def _stop_upload_worker(jobs_queue, thread):
+    """Let the upload thread finish what it holds and end (called by ``SubVolume.close`` or when a volume is collected)."""
+    import threading
+
+    jobs_queue.put(None)
+    if thread.is_alive() and thread is not threading.current_thread():
+        thread.join(timeout=30.0)
+
+
 class SubVolume(_HasWorld):
     material: SubVolumeMaterial
 
@@ -215,6 +224,18 @@ class SubVolume(_HasWorld):
         if jobs:
             self._submit_uploads(jobs)
 
+    def close(self):
+        """Stop the upload thread (after the loads it already holds) and free the rings and every other device
+        allocation of this volume now, instead of when the object is collected."""
+        stop = getattr(self, "_worker_stop", None)
+        if stop is not None:
+            stop()
+        self._worker = None
+        self._inflight.clear()
+        self._completed = self._submitted
+        self._out_cache, self._ob_cache = {}, {}
+        self._rings.close()
+
     # -- asynchronous streaming ------------------------------------------------------
     @staticmethod
     def _prioritise(jobs):
@@ -239,16 +260,21 @@ class SubVolume(_HasWorld):
         import queue
         import threading
 
+        import weakref
+
         handle = self._rings.handle                       # create the context on this thread
         for b in self.wrapping_buffers:
-            b._async_owner = self
+            b._async_owner = weakref.ref(self)
         if self._worker is None:
-            self._jobs = queue.Queue()
+            # the thread holds the queue, the result list and the context handle — not the volume: a volume that is
+            # dropped is collected, and its finalizer stops the thread BEFORE the device context goes away
+            jobs_queue = self._jobs = queue.Queue()
+            inflight = self._inflight
 
             def run():
                 lib = N.lib()
                 while True:
-                    item = self._jobs.get()
+                    item = jobs_queue.get()
                     if item is None:
                         return
                     buffer, pieces = item
@@ -259,10 +285,12 @@ class SubVolume(_HasWorld):
                         N.check(lib.svr_upload_ticket(handle, C.byref(ticket)), "svr_upload_ticket")
                     except BaseException as exc:          # surfaced by poll_uploads on the render thread
                         error = exc
-                    self._inflight.append((buffer, ticket.value, error))
+                    inflight.append((buffer, ticket.value, error))
+                    del item, buffer, pieces              # an idle thread keeps no level (and through it no volume) alive
 
             self._worker = threading.Thread(target=run, name="svr-upload", daemon=True)
             self._worker.start()
+            self._worker_stop = weakref.finalize(self, _stop_upload_worker, jobs_queue, self._worker)
         # one job per level, coarse levels first: each gets its own ticket and is published as soon as
         # ITS chunks have landed
         for job in self._prioritise(jobs):

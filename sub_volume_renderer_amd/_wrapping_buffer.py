@@ -44,9 +44,12 @@ class DeviceRings:
         self.density_storage = density_storage
         self.labels = bool(labels)            # False: a volume without segmentation, no label rings at all
         self._handle = None
+        self._closed = False
 
     @property
     def handle(self):
+        if self._closed:
+            raise RuntimeError("this volume's device context was closed")
         if self._handle is None:
             lib = N.lib()
             descs = (N.LodDesc * len(self.ring_shapes))()
@@ -66,6 +69,7 @@ class DeviceRings:
         return self._handle
 
     def close(self):
+        self._closed = True
         if self._handle is not None:
             N.lib().svr_destroy(self._handle)
             self._handle = None
@@ -182,7 +186,7 @@ class WrappingBuffer:
         self._roi_px: Roi | None = None
         self._pending_async = None
         self._wanted_roi = None          # newest request that arrived while an asynchronous load was in flight
-        self._async_owner = None         # the SubVolume whose upload worker serves this buffer
+        self._async_owner = None         # weakref to the SubVolume whose upload worker serves this buffer
         self._current_logical_roi_in_chunks: Roi | None = None
         self._scale_factor = (1.0, 1.0, 1.0)
         self._state_dirty = True
@@ -284,7 +288,7 @@ class WrappingBuffer:
         self.publish()
 
     def _drain_async(self):
-        owner = self._async_owner
+        owner = self._async_owner() if self._async_owner is not None else None      # a weak reference: buffers do not keep their volume alive
         if owner is None:
             raise RuntimeError("an asynchronous load is pending on this buffer and nobody owns it")
         owner.poll_uploads(wait=True)

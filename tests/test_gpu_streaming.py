@@ -387,3 +387,41 @@ def test_rings_of_4_gib_in_total_keep_the_span_kernel_with_one_resource_per_lod(
         res = scene.volume.render(scene.camera, spec.width, spec.height, count_steps=True)
         torch.cuda.synchronize()
         _assert_frame(res, lmip.render_spec(small), "big rings, mip")
+
+
+def test_a_dropped_volume_stops_its_upload_thread_and_frees_its_rings():
+    """The upload thread holds the job queue and the context handle, not the volume: dropping a volume that has
+    streamed asynchronously ends the thread (after the loads it holds) before the device context is destroyed;
+    ``close()`` does the same at once."""
+    import gc
+    import weakref
+
+    import torch
+
+    spec = testing.synthetic_spec(96, 128, 80, inside=True, chunk_shapes=[(8, 8, 16), (4, 4, 16), (2, 2, 16)],
+                                  ring_shapes=[(5, 5, 3), (8, 8, 3), (8, 8, 2)])
+    eye = np.array(spec.cam_position)
+    d = np.array(spec.cam_target) - eye
+    d = d / np.linalg.norm(d)
+    for explicit in (False, True):
+        scene = testing.build(spec)
+        vol = scene.volume
+        for k in range(1, 4):
+            vol.center_on_position(tuple(eye + d * 6.0 * k), asynchronous=True)
+            vol.render(scene.camera, spec.width, spec.height)
+        worker = vol._worker
+        assert worker is not None and worker.is_alive()
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        ref = weakref.ref(vol)
+        if explicit:
+            vol.close()
+            assert not worker.is_alive()
+            with pytest.raises(RuntimeError, match="closed"):
+                vol.render(scene.camera, spec.width, spec.height)
+        del scene, vol
+        gc.collect()
+        worker.join(timeout=10.0)
+        assert not worker.is_alive()
+        assert ref() is None
+        assert torch.cuda.mem_get_info()[0] > free_before          # the rings went back to the device
