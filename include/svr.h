@@ -14,6 +14,14 @@
  * Plain pointers and sizes only; no torch / HIP types in any signature
  * (streams travel as void*).  Every function returns 0 on success and a
  * negative svr_status on failure; svr_last_error() gives the message.
+ *
+ * Threads.  A context has ONE render thread: svr_set_lod_state, svr_set_material, svr_set_variant, svr_render,
+ * svr_time_render, svr_gather_tiles and the svr_comm_* calls of one context must not run concurrently with one
+ * another (renders may go to different HIP streams, one after the other).  svr_upload_region / _device,
+ * svr_upload_ticket, svr_ticket_pending, svr_mark_uploads and svr_uploads_pending may be called from ONE other
+ * thread at the same time (the streaming worker): uploads of a context are serialised by a mutex, and they are
+ * ordered on the device behind every render still in flight.  Different contexts are independent.
+ * svr_last_error() is per thread.
  */
 #ifndef SVR_H
 #define SVR_H
