@@ -449,11 +449,12 @@ __device__ __forceinline__ typename Texel<ESH>::type lds_texel(uint32_t a) {
 }
 
 // texel fetch through the range-checked buffer resource
+// (soff: a wave-uniform byte offset that rides in the instruction's scalar-offset operand, for free)
 template <int ESH>
-__device__ __forceinline__ typename Texel<ESH>::type fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
-    if constexpr (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
-    else if constexpr (ESH == 1) return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)off, 0, 0);
-    else return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, 0, 0);
+__device__ __forceinline__ typename Texel<ESH>::type fetch_density(__amdgpu_buffer_rsrc_t rsrc, uint32_t off, uint32_t soff = 0u) {
+    if constexpr (ESH == 2) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, (int)soff, 0));
+    else if constexpr (ESH == 1) return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)off, (int)soff, 0);
+    else return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off, (int)soff, 0);
 }
 
 // a*b + c on the 24-bit integer multiplier (one full-rate-class VALU op); a, b < 2^24
@@ -985,32 +986,42 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t cbase = Ps->lod[first].cell_base;
                     const uint32_t cdx = Ps->lod[first].cdim[0], cdy = Ps->lod[first].cdim[1], cdz = Ps->lod[first].cdim[2];
                     bool vetoed = false, tracking_only = false;
+                    // cell coordinates of the sample at iteration n (not beyond the lane's last sample): border 0 of the first
+                    // test; every later test inherits it from its predecessor's last border
+                    uint32_t c0x, c0y, c0z;
+                    {
+                        const float i0 = fminf((float)n, (float)(nsteps - 1));
+                        c0x = ((uint32_t)(int)((i0 * Rtx + Rsx) * ssx) + (uint32_t)L.addw[0]) >> cs;
+                        c0y = ((uint32_t)(int)((i0 * Rty + Rsy) * ssy) + (uint32_t)L.addw[1]) >> cs;
+                        c0z = ((uint32_t)(int)((i0 * Rtz + Rsz) * ssz) + (uint32_t)L.addw[2]) >> cs;
+                    }
                     while (run >= 4 * sb) {
                         const bool live = alive && !finished && n < nsteps;
                         // unwrapped cell coordinates ((index + addw) >> cs, in [0, 2 * cells)) of the samples at the 5
-                        // stretch borders: iterations n, n + 8B, n + 16B, n + 24B and the LAST one of the group,
-                        // n + 32B - 1 (the next iteration may already lie beyond this run: another LOD, another wrap);
-                        // none beyond the lane's last sample
-                        const float lastf = fminf((float)(nsteps - 1), (float)n + 4.0f * reach - 1.0f);
+                        // stretch borders: iterations n, n + 8B, n + 16B, n + 24B and n + 32B — the first border of the
+                        // next test, which inherits it — or, when this run ends with the group, its LAST iteration,
+                        // n + 32B - 1 (the next one lies beyond this run: another LOD, another wrap); none beyond the
+                        // lane's last sample
+                        const float lastf = fminf((float)(nsteps - 1), (float)n + 4.0f * reach - (run > 4 * sb ? 0.0f : 1.0f));
                         uint32_t px[5], py[5], pz[5];
+                        px[0] = c0x; py[0] = c0y; pz[0] = c0z;
 #pragma unroll
-                        for (int g = 0; g < 6; g += 2) {
+                        for (int g = 1; g < 5; g += 2) {
                             const float i0 = (float)n + reach * (float)g;
                             const float2_t iter = { fminf(i0, lastf), fminf(i0 + reach, lastf) };
                             const Idx2 q = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                             px[g] = (q.x0 + (uint32_t)L.addw[0]) >> cs; py[g] = (q.y0 + (uint32_t)L.addw[1]) >> cs; pz[g] = (q.z0 + (uint32_t)L.addw[2]) >> cs;
-                            if (g + 1 < 5) {
-                                px[g + 1] = (q.x1 + (uint32_t)L.addw[0]) >> cs; py[g + 1] = (q.y1 + (uint32_t)L.addw[1]) >> cs;
-                                pz[g + 1] = (q.z1 + (uint32_t)L.addw[2]) >> cs;
-                            }
+                            px[g + 1] = (q.x1 + (uint32_t)L.addw[0]) >> cs; py[g + 1] = (q.y1 + (uint32_t)L.addw[1]) >> cs;
+                            pz[g + 1] = (q.z1 + (uint32_t)L.addw[2]) >> cs;
                         }
+                        c0x = px[4]; c0y = py[4]; c0z = pz[4];
                         texel_t v[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             // the block that starts at the smaller cell coordinate per axis, wrapped onto the ring of cells
                             uint32_t bx = min(px[g], px[g + 1]), by = min(py[g], py[g + 1]), bz = min(pz[g], pz[g + 1]);
                             bx = min(bx, bx - cdx); by = min(by, by - cdy); bz = min(bz, bz - cdz);
-                            v[g] = fetch_density<ESH>(crsrc, (mad24(mad24(bz, cdy, by), cdx, bx) << ESH) + cbase);
+                            v[g] = fetch_density<ESH>(crsrc, (__umul24(__umul24(bz, cdy) + by, cdx) + bx) << ESH, cbase);
                         }
                         const texel_t m = texel_max(texel_max(texel_abs(v[0]), texel_abs(v[1])), texel_max(texel_abs(v[2]), texel_abs(v[3])));
                         // a lane that tracks a maximum, moves too fast for the test, or passes a block that may hold a
