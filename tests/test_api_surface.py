@@ -40,6 +40,33 @@ def test_abi_version_and_struct_sizes():
     assert ctypes.sizeof(_native.Frame) == 32
 
 
+def test_header_is_plain_c_and_the_c_example_links_against_the_library_alone(tmp_path):
+    """include/svr.h compiles as strict C99 / C11 and as C++17 without a warning, and examples/c_abi_demo.c links
+    against libsvr_hip.so + the HIP runtime and nothing of Python or torch (it RUNS in tests/test_gpu_c_consumer.py)."""
+    import shutil
+    import subprocess
+
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    if gcc is None or gxx is None:
+        pytest.skip("no C / C++ compiler on this machine")
+    unit = tmp_path / "unit.c"
+    unit.write_text('#include "svr.h"\nint main(void) { return svr_abi_version() == SVR_ABI_VERSION ? 0 : 1; }\n')
+    strict = ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only"]
+    subprocess.run([gcc, "-std=c99", *strict, str(unit)], check=True)
+    subprocess.run([gcc, "-std=c11", *strict, str(unit)], check=True)
+    subprocess.run([gxx, "-std=c++17", *strict, "-x", "c++", str(unit)], check=True)
+    if not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no ROCm headers: the example needs hip_runtime_api.h")
+    _native.lib()                                           # built (and loadable) before linking against it
+    csrc = os.path.join(ROOT, "sub_volume_renderer_amd", "csrc")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run([gcc, "-O1", "-std=c11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", csrc, "-lsvr_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    linked = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libsvr_hip.so" in linked and "torch" not in linked and "python" not in linked
+
+
 def test_create_without_gpu_fails_loudly():
     import torch
 
