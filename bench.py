@@ -501,8 +501,8 @@ def main():
         loop = FrameLoop(1)
 
         def fly(mode, asynchronous):
-            """Back to the start, W untimed frames, then K timed ones; per-frame wall times (frame k = render, wait
-            for it as a display would, then move the ring windows)."""
+            """Back to the start, W untimed frames, then K timed ones; per-frame wall times (frame k = enqueue the render,
+            move the ring windows while it runs, wait for it as a display would)."""
             set_mode(mode == "full")
             vol.poll_uploads(wait=True)
             vol.center_on_position(poses[0][0])                            # blocking: rings as at the start
@@ -521,11 +521,11 @@ def main():
                     torch.cuda.synchronize()
                     t_start = time.perf_counter()
                 t = time.perf_counter()
-                loop.frame(cams[k])
+                loop.frame(cams[k])                                            # enqueue the draw ...
                 loop.drain()
-                torch.cuda.current_stream(dev).synchronize()
-                vol.center_on_position(eye, asynchronous=asynchronous)
-                if k >= args.warmup:
+                vol.center_on_position(eye, asynchronous=asynchronous)         # ... plan / start the window moves beside it
+                torch.cuda.current_stream(dev).synchronize()                   # (the order of the reference's do_draw:
+                if k >= args.warmup:                                           #  scripts/multi_scale.py:76-80), then wait for the frame
                     times.append((time.perf_counter() - t) * 1e3)
             torch.cuda.synchronize()
             if collective:

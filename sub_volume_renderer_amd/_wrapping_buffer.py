@@ -259,6 +259,9 @@ class WrappingBuffer:
         snapped = self.get_snapped_roi_in_pixels(logical_roi_in_pixels)
         if not self.can_load_logical_roi(logical_roi_in_pixels) or snapped.empty:
             return None
+        if (self._pending_async is None and self._roi_px is not None and self._current_logical_roi_in_chunks is not None
+                and snapped == self._roi_px):
+            return snapped, self._current_logical_roi_in_chunks, []      # the window did not move off its chunk grid: nothing to do
         in_chunks = snapped / self.chunk_shape_in_pixels
         if self._current_logical_roi_in_chunks is None:
             slabs = [in_chunks]
@@ -312,7 +315,8 @@ class WrappingBuffer:
             return None
         snapped, in_chunks, pieces = plan
         if not pieces:                                   # nothing new to fetch: plain state change
-            self._current_logical_roi_in_pixels = snapped
+            if snapped != self._roi_px:                  # (an unchanged window leaves the uniform alone)
+                self._current_logical_roi_in_pixels = snapped
             self._current_logical_roi_in_chunks = in_chunks
             return None
         old = self._roi_px
