@@ -139,6 +139,8 @@ def main():
     bricks = 0
     bad = skipped = hits = 0
     for seed in range(first, first + cases):
+        if (seed - first) % 1000 == 999:                     # long campaigns: a sign of life once a minute or so
+            print(f"... {seed - first + 1} of {cases} cases, {bad} mismatching so far", file=sys.stderr, flush=True)
         try:
             spec, region, variant = random_spec(seed, brick)
             ovol = lmip.oracle_volume(spec)
