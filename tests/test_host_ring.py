@@ -173,6 +173,24 @@ def test_plan_sequence_matches_oracle(seed):
         assert tuple(u["current_logical_shape_in_pixels"]) == w["shape"]
 
 
+def test_a_window_that_stays_on_its_chunk_grid_plans_nothing():
+    """Requests that snap to the resident window (a camera moving inside one chunk) return the resident state and no
+    pieces — without any ROI subtraction — and never disagree with the full computation."""
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 255, (40, 40, 40), dtype=np.uint8)
+    seg = np.zeros((40, 40, 40), np.uint32)
+    prod = WrappingBuffer(data, seg, (4, 4, 4), (4, 4, 4))
+    snapped, in_chunks, pieces = prod.plan_logical_roi(Roi((9, 9, 9), (10, 10, 10)))
+    assert pieces and (tuple(snapped.offset), tuple(snapped.shape)) == ((8, 8, 8), (12, 12, 12))
+    prod._current_logical_roi_in_pixels, prod._current_logical_roi_in_chunks = snapped, in_chunks
+    for off in ((8, 8, 8), (9, 9, 10), (10, 10, 10)):                  # all snap to [8, 20)^3
+        again = prod.plan_logical_roi(Roi(off, (10, 10, 10)))
+        assert again == (snapped, in_chunks, [])
+        assert subtract_rois(again[1], in_chunks) == []
+    moved = prod.plan_logical_roi(Roi((11, 10, 10), (10, 10, 10)))   # crosses into the next chunk along axis 0
+    assert moved[2] and moved[0] != snapped
+
+
 def test_unaligned_ring_sized_roi_asserts_like_reference():
     """can_load only checks the unsnapped shape (_wrapping_buffer.py:145-158), so a ring-sized
     ROI that is not chunk-aligned grows past the ring and trips the wrap assertion (:215-221)
