@@ -212,7 +212,7 @@ __device__ __forceinline__ void shade_and_store(const MarchParams& P, size_t o, 
             color = make_float4(0.f, 0.f, 0.f, 1.f); cls = SVR_PIX_MISS;
         } else {
             float v = (h.sample - P.clim0) / (P.clim1 - P.clim0);        // sampled_value_to_color
-            v = powf(v, P.gamma);
+            if (P.gamma != 1.0f) v = powf(v, P.gamma);                    // pow(v, 1) is v: the default gamma costs nothing
             float phys = P.colorspace_srgb ? srgb2physical(v) : v;        // raycast.wgsl:71-75
             label = sample_label<NL>(P, h.coord.x, h.coord.y, h.coord.z); // raycast.wgsl:81
             f4 wp = mat_vec(P.world, h.coord.x - 0.5f, h.coord.y - 0.5f, h.coord.z - 0.5f, 1.0f);
@@ -398,10 +398,17 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
     // (v_rcp_f32, 1 ulp: __frcp_rn is a correctly rounded 1 / x, i.e. a full 11-instruction division)
     const float guess = ceilf(((float)thresh * __builtin_amdgcn_rcpf(size * scale) - start) * __builtin_amdgcn_rcpf(step));
     int j = (int)fminf(fmaxf(guess, 0.0f), (float)n);
+    // The guess is nearly always the answer itself (the f32 chain moves it by one iteration at most): j is the first
+    // crossing iff the index has not crossed at j - 1 and has at j.  Two evaluations settle that; the search loops —
+    // which the compiler turns into 8 evaluations per trip, ~60 instructions even for a trip that finds nothing to
+    // do — only run when some lane's guess was off.
+    const bool settled = (j == 0 || !pred(j - 1)) && (j == n || pred(j));
+    if (__builtin_amdgcn_ballot_w64(!settled) != 0) {
 #pragma nounroll
-    while (j > 0 && pred(j - 1)) --j;
+        while (j > 0 && pred(j - 1)) --j;
 #pragma nounroll
-    while (j < n && !pred(j)) ++j;
+        while (j < n && !pred(j)) ++j;
+    }
     return j;
 }
 
