@@ -386,8 +386,9 @@ __device__ __forceinline__ int axis_voxel(int i, float start, float step, float 
 
 // First iteration j in [0, n] at which the (monotone) voxel index has crossed `thresh`
 // in its direction of travel: ic(j) >= thresh for step > 0, ic(j) < thresh for step < 0.
-// A zero step never crosses: returns 0 if the condition already holds, else n.
-__device__ __forceinline__ int first_cross(int n, float start, float step, float size, float scale, int thresh) {
+// A zero step never crosses: returns 0 if the condition already holds, else n.  The result is only defined for lanes
+// that pass wanted = true.
+__device__ __forceinline__ int first_cross(int n, float start, float step, float size, float scale, int thresh, bool wanted = true) {
     const bool inc = step > 0.0f;
     auto pred = [&](int j) {
         const int v = axis_voxel(j, start, step, size, scale);
@@ -402,12 +403,14 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
     // crossing iff the index has not crossed at j - 1 and has at j.  Two evaluations settle that; the search loops —
     // which the compiler turns into 8 evaluations per trip, ~60 instructions even for a trip that finds nothing to
     // do — only run when some lane's guess was off.
+    // (`wanted`: the caller only uses this lane's result then; the other lanes of the wave neither trigger nor walk the
+    // loops, whatever their guess was)
     const bool settled = (j == 0 || !pred(j - 1)) && (j == n || pred(j));
-    if (__builtin_amdgcn_ballot_w64(!settled) != 0) {
+    if (__builtin_amdgcn_ballot_w64(wanted && !settled) != 0) {
 #pragma nounroll
-        while (j > 0 && pred(j - 1)) --j;
+        while (wanted && j > 0 && pred(j - 1)) --j;
 #pragma nounroll
-        while (j < n && !pred(j)) ++j;
+        while (wanted && j < n && !pred(j)) ++j;
     }
     return j;
 }
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 int j = p0 ? 0 : nsteps;
                 const bool need = !p0 && p1;
                 if (__builtin_amdgcn_ballot_w64(need) != 0) {
-                    const int js = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], T);
+                    const int js = first_cross(nsteps, st, sp, P.size[ax], L.scale[ax], T, need);
                     j = need ? js : j;
                 }
                 return j;
