@@ -252,10 +252,12 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
  * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
- * bits 11-12 timing experiments ONLY, results are wrong: 11 = do not wait for brick loads, 12 = skip the march
+ * bits 11-12 reserved: SVR_ERR_INVALID.  (Builds made with -DSVR_EXPERIMENTS — tools/ab_build.py, never the shipped
+ *            library — use them for timing experiments that render WRONG pixels, and read the SVR_* environment
+ *            switches listed in tools/README.md; the shipped library reads only SVR_PACK_THREADS, the number of host
+ *            threads that pack upload blocks.)
  * bits 13-15 block -> tile placement: 0 = 64x64-pixel chunks of tiles sorted by the length of their rays for the draw's
- *            camera, longest first, dealt to the XCDs in snake order (default; SVR_STATIC_PLACEMENT=1 in the environment:
- *            the same chunks in raster order, round-robin),
+ *            camera, longest first, dealt to the XCDs in snake order (default),
  *            1 = one contiguous run of tiles per XCD, 2..6 = single tiles, 64x32, 32x32, 128x64, 32x16 chunks in raster order,
  *            7 = 64x64 chunks in raster order (camera-independent; about 1 % faster than 0 when several frames are kept in
  *            flight on separate streams, 4 % slower for one frame at a time)

@@ -11,25 +11,27 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <rccl/rccl.h>      // types and prototypes only: every call goes through a dlsym'd pointer of the prototype's own type
+
 #include "svr_internal.h"
+
+static_assert(SVR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "svr.h carries ncclUniqueId as SVR_COMM_ID_BYTES opaque bytes");
+static_assert(sizeof(ncclUniqueId) == SVR_COMM_ID_BYTES, "ncclUniqueId layout");
 
 namespace {
 
-typedef int ncclResult_t;                         // ncclSuccess == 0
-typedef struct ncclComm* ncclComm_t;
-struct ncclUniqueId { char internal[128]; };      // NCCL_UNIQUE_ID_BYTES (rccl.h:40-43)
-enum { kNcclInt8 = 0 };                           // ncclInt8 / ncclChar (rccl.h ncclDataType_t)
-
 struct Rccl {
     void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;                                 // rccl.h:187
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;          // rccl.h:220
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;                                    // rccl.h:260
-    const char*  (*GetErrorString)(ncclResult_t) = nullptr;                               // rccl.h:339
-    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;   // rccl.h:700
-    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;         // rccl.h:722
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
+    // pointer types are taken from rccl.h's own declarations, so a changed signature fails to compile here instead of
+    // drifting silently behind dlsym
+    decltype(&ncclGetUniqueId)    GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank)   CommInitRank = nullptr;
+    decltype(&ncclCommDestroy)    CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclSend)           Send = nullptr;
+    decltype(&ncclRecv)           Recv = nullptr;
+    decltype(&ncclGroupStart)     GroupStart = nullptr;
+    decltype(&ncclGroupEnd)       GroupEnd = nullptr;
     std::string error;
 };
 
@@ -73,7 +75,7 @@ int rccl_fail(const char* what, ncclResult_t e) {
 #define SVR_RCCL_TRY(expr)                                        \
     do {                                                          \
         const ncclResult_t e_ = (expr);                           \
-        if (e_ != 0) return rccl_fail(#expr, e_);                 \
+        if (e_ != ncclSuccess) return rccl_fail(#expr, e_);                 \
     } while (0)
 
 }  // namespace
@@ -104,7 +106,7 @@ int svr_comm_init(svr_ctx* c, const char id_bytes[SVR_COMM_ID_BYTES], int rank, 
     ncclComm_t comm = nullptr;
     const ncclResult_t e = r.CommInitRank(&comm, nranks, id, rank);
     (void)hipSetDevice(prev);
-    if (e != 0) return rccl_fail("ncclCommInitRank", e);
+    if (e != ncclSuccess) return rccl_fail("ncclCommInitRank", e);
     c->comm = comm; c->comm_rank = rank; c->comm_size = nranks;
     return SVR_OK;
 }
@@ -135,21 +137,21 @@ int svr_gather_tiles(svr_ctx* c, int nplanes, const void* const* local, void* co
     DeviceGuard guard(c->device);
     // every plane of every peer in ONE group: the transfers progress concurrently, one per xGMI link
     SVR_RCCL_TRY(r.GroupStart());
-    ncclResult_t e = 0;
-    for (int p = 0; p < nplanes && e == 0; ++p) {
+    ncclResult_t e = ncclSuccess;
+    for (int p = 0; p < nplanes && e == ncclSuccess; ++p) {
         const size_t n = bytes_per_rank[p];
         if (n == 0) continue;
         if (is_root) {
             char* base = static_cast<char*>(gathered[p]);
-            for (int k = 0; k < c->comm_size && e == 0; ++k)
-                if (k != root) e = r.Recv(base + (size_t)k * n, n, kNcclInt8, k, comm, s);
+            for (int k = 0; k < c->comm_size && e == ncclSuccess; ++k)
+                if (k != root) e = r.Recv(base + (size_t)k * n, n, ncclInt8, k, comm, s);
         } else {
-            e = r.Send(local[p], n, kNcclInt8, root, comm, s);
+            e = r.Send(local[p], n, ncclInt8, root, comm, s);
         }
     }
     const ncclResult_t ge = r.GroupEnd();
-    if (e != 0) return rccl_fail("ncclSend/ncclRecv", e);
-    if (ge != 0) return rccl_fail("ncclGroupEnd", ge);
+    if (e != ncclSuccess) return rccl_fail("ncclSend/ncclRecv", e);
+    if (ge != ncclSuccess) return rccl_fail("ncclGroupEnd", ge);
     if (is_root)                                     // root's own region: a device copy on the same stream
         for (int p = 0; p < nplanes; ++p)
             if (bytes_per_rank[p])

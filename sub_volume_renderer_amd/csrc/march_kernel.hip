@@ -726,7 +726,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     __amdgpu_buffer_rsrc_t rsrc_all = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(P.density_all), 0, (int)P.density_all_bytes, 0x00020000);
 
-    bool found = false, finished = (P.dbg_nowait & 2) != 0;    // instruction-count experiments: prologue + epilogue only
+#ifdef SVR_EXPERIMENTS
+    const int dbg_nowait = P.dbg_nowait, brick_pow2 = P.brick_pow2;       // timing experiments (wrong pixels) / round-1 brick layout
+#else
+    constexpr int dbg_nowait = 0, brick_pow2 = 0;                         // the shipped kernel carries neither
+#endif
+    bool found = false, finished = (dbg_nowait & 2) != 0;      // instruction-count experiments: prologue + epilogue only
     float local_max = 0.f, samp = 0.f;
     int hit_i = 0, since = 0;
     uint32_t steps = 0;
@@ -1098,8 +1103,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     // iteration then start in 8 different bank quads instead of 1, 2 or 4 (power-of-two pitches:
                     // 70 % of the LDS cycles were bank conflicts), and only the ngx groups the box really spans
                     // are fetched (a pitch rounded up to a power of two fetched up to twice that).
-                    const int gp = P.brick_pow2 ? (ngx <= 1 ? 1 : 1 << (32 - __builtin_clz(ngx - 1))) : (ngx | 1);
-                    const int pz = P.brick_pow2 ? ny * gp : ((ny * gp) | 1);
+                    const int gp = brick_pow2 ? (ngx <= 1 ? 1 : 1 << (32 - __builtin_clz(ngx - 1))) : (ngx | 1);
+                    const int pz = brick_pow2 ? ny * gp : ((ny * gp) | 1);
                     if (ny >= 512 || pz * nz * 16 > P.brick_bytes) {         // does not fit
                         if (brick_mode > 1) { --brick_mode; continue; }       // retry with half the slab
                         brick_mode = 0; break;                                // march direct from here on
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t*)lds_all);
                     const uint32_t bk = lds_base + (uint32_t)wave_lds - (uint32_t)(((lz * pz + ly * gp) << 4) + (gx0 << ESH));
                     lap(3);
-                    if (!(P.dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(dbg_nowait & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lap(4);
                     // one dot2 on the packed (y, z): y * rowpitch + z * planepitch + (x + bk)
                     const uint32_t kyz = (uint32_t)(gp << 4) | ((uint32_t)(pz << 4) << 16);

@@ -262,7 +262,7 @@ hipError_t svr_launch_scatter(const ScatterArgs& a, hipStream_t stream) {
          a.lstride[1] % 16 == 0 && a.lstride[2] % 16 == 0);
     const bool geo_ok = (a.shape[0] & 15) == 0 && (a.dst_off[0] & 15) == 0 && (a.ring[0] & 15) == 0 &&
                         aligned16(a.ring_density) && aligned16(a.ring_labels) && n / 16 < 0x7fffffffu;
-    static const bool force_general = getenv("SVR_SCATTER_GENERAL") != nullptr;      // A/B measurements only
+    static const bool force_general = svr_exp_env_set("SVR_SCATTER_GENERAL");        // A/B measurements (-DSVR_EXPERIMENTS builds)
     if (d_ok && l_ok && geo_ok && !force_general) {
         const uint32_t gpr = (uint32_t)a.shape[0] / 16u, total = (uint32_t)(n / 16);
         const dim3 grid((total + 255u) / 256u), block(256);

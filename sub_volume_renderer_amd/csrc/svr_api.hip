@@ -251,6 +251,9 @@ int svr_set_material(svr_ctx* c, const svr_material* m) {
 
 int svr_set_variant(svr_ctx* c, int variant) {
     SVR_REQUIRE(c, "svr_set_variant: null ctx");
+    // bits 11-12 are timing experiments that render WRONG pixels: only a -DSVR_EXPERIMENTS build knows them
+    SVR_REQUIRE((variant & 0x1800 & ~SVR_EXP_VARIANT_BITS) == 0,
+                "svr_set_variant: bits 11-12 (timing experiments) exist only in builds made with -DSVR_EXPERIMENTS");
     c->variant = variant;
     return SVR_OK;
 }
@@ -420,7 +423,7 @@ static void pack_rows(const char* dsrc, size_t des, const int64_t* dst_strides, 
     unsigned hw = std::thread::hardware_concurrency();
     // (12 or 16 threads, and streaming stores into the slot, measured no faster)
     int nt = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), bytes / ((size_t)512 << 10));
-    if (const char* e = getenv("SVR_PACK_THREADS")) nt = std::max(1, atoi(e));
+    if (const char* e = getenv("SVR_PACK_THREADS")) nt = std::max(1, atoi(e));      // deployment setting (include/svr.h), not an experiment
     nt = (int)std::min<int64_t>(std::max(nt, 1), std::max<int64_t>(1, nrows / 2));
     const int64_t per = (nrows + nt - 1) / nt;
     PackPool::get().run(nt, [&](int t) {
@@ -467,7 +470,7 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
     // the bus and block k-1 is being scattered, so a region of one or two slots' worth still overlaps the three.
     const size_t region_bytes = row_bytes * (size_t)shape[1] * (size_t)shape[2];
     size_t block_bytes = std::min(c->slot_bytes - 32, std::max<size_t>((size_t)4 << 20, region_bytes / 8));
-    if (const char* e = getenv("SVR_UPLOAD_BLOCK_MIB")) block_bytes = std::min(c->slot_bytes - 32, std::max<size_t>(1, (size_t)atoi(e)) << 20);
+    if (const int mib = svr_exp_env_int("SVR_UPLOAD_BLOCK_MIB", 0)) block_bytes = std::min(c->slot_bytes - 32, std::max<size_t>(1, (size_t)mib) << 20);
     const int64_t rows_max = std::max<int64_t>(1, (int64_t)(block_bytes / row_bytes));
     const int64_t plane_rows = shape[1];
     const int64_t total_rows = plane_rows * shape[2];
@@ -886,18 +889,18 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
     P.orient = (c->variant & 1024) ? 0 : 1;
-    P.dbg_nowait = (c->variant >> 11) & 3;          // bit 11: no brick wait, bit 12: skip the march loop
+    P.dbg_nowait = ((c->variant & SVR_EXP_VARIANT_BITS) >> 11) & 3;      // -DSVR_EXPERIMENTS builds: bit 11 no brick wait, bit 12 skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     const int brick_mask = P.brick_lod_mask;
     // Every wave starts with brick slabs of twice the plain length (the staged bytes per sample fall with the
     // slab length) and drops to the plain length at its first box that does not fit; variant bit 2: never long.
     P.slab_long = (c->variant & 4) ? 0 : 1;
-    static const bool brick_pow2 = getenv("SVR_BRICK_POW2") != nullptr;       // A/B measurements only
+    static const bool brick_pow2 = svr_exp_env_set("SVR_BRICK_POW2");         // A/B measurements (-DSVR_EXPERIMENTS builds)
     P.brick_pow2 = brick_pow2 ? 1 : 0;
     // LDS per wave: 8 KiB holds the box of a 16..64-iteration slab of byte voxels and lets 20 one-wave blocks share
     // a CU's 160 KiB.  2- and 4-byte voxels fit shorter slabs in the same 8 KiB; 16 KiB for them (10 waves per CU)
     // measured slower: K1 full, f32 rings 1.60 ms against 1.31 ms (SVR_BRICK_BYTES: experiments)
-    static const int brick_bytes_env = getenv("SVR_BRICK_BYTES") ? atoi(getenv("SVR_BRICK_BYTES")) : 0;
+    static const int brick_bytes_env = svr_exp_env_int("SVR_BRICK_BYTES", 0);
     P.brick_bytes = brick_bytes_env >= 1024 && brick_bytes_env <= 65536 ? (brick_bytes_env & ~15) : 8192;
     {   // vanishing point of the volume's x axis: (proj*cam) * (world * (1,0,0,0))
         const float ex[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
@@ -915,7 +918,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         if (rc_order) return rc_order;
         // default placement: the same 64x64-pixel chunks, but sorted by the length of their rays for THIS camera
         // (longest first, snake-dealt to the XCDs); SVR_STATIC_PLACEMENT keeps the camera-independent table (A/B)
-        static const bool static_placement = getenv("SVR_STATIC_PLACEMENT") != nullptr;
+        static const bool static_placement = svr_exp_env_set("SVR_STATIC_PLACEMENT");
         if (!static_placement && ((c->variant >> 13) & 7) == 0 && P.tiles_x * P.tiles_y > 0) {
             const int rc_lpt = tile_order_by_cost_for(c, P, bw, bh, stream, &P.tile_order);
             if (rc_lpt) return rc_lpt;
@@ -952,7 +955,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         {   // brick slabs (u8 rings): about 12 ring voxels of travel per slab (coarser LODs advance less per
             // iteration); rows in 16-byte groups, indices below 2^15 for the packed (y, z) brick address
             const float smax = fmaxf(Q.scale[0], fmaxf(Q.scale[1], Q.scale[2]));
-            static const int slab_shift = getenv("SVR_SLAB_SHIFT") ? atoi(getenv("SVR_SLAB_SHIFT")) : 0;     // A/B measurements
+            static const int slab_shift = svr_exp_env_int("SVR_SLAB_SHIFT", 0);     // A/B measurements (-DSVR_EXPERIMENTS builds)
             const int slab = std::max(8, (smax > 0.75f ? 16 : (smax > 0.375f ? 32 : 64)) >> slab_shift);
             // (ring rows must be whole 16-byte groups: 16 / 8 / 4 voxels for u8 / u16 / f32 rings)
             bool ok = ((Q.ring[0] * des) & 15u) == 0u && (brick_mask >> l & 1);
@@ -981,7 +984,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
                       (mip_like || (P.lmip_threshold_raw > 0u &&
                       (c->density_storage == SVR_F32 ? (m.lmip_threshold > 0.0f && m.lmip_threshold < INFINITY)
                                                      : P.lmip_threshold_raw <= (c->density_storage == SVR_U16 ? 65535u : 255u))));
-    static const int skip_flags_env = getenv("SVR_SKIP_FLAGS") ? atoi(getenv("SVR_SKIP_FLAGS")) : 1;      // A/B measurements
+    static const int skip_flags_env = svr_exp_env_int("SVR_SKIP_FLAGS", 1);      // A/B measurements (-DSVR_EXPERIMENTS builds)
     P.skip_flags = (skip_flags_env & 1) | (mip_like ? 2 : 0);
     P.cells_all = skip ? c->cells_dil_all : nullptr;
     P.cells_all_bytes = skip ? (uint32_t)c->cells_all_bytes : 0u;

@@ -12,6 +12,20 @@
 
 #include "../../include/svr.h"
 
+// Experiment surface: environment switches and the results-changing timing bits of svr_set_variant exist only in
+// builds made with -DSVR_EXPERIMENTS (tools/ab_build.py name=-DSVR_EXPERIMENTS); the shipped library reads no
+// environment variable that alters the march and rejects those variant bits.
+#ifdef SVR_EXPERIMENTS
+#include <stdlib.h>
+static inline int  svr_exp_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool svr_exp_env_set(const char* name) { return getenv(name) != nullptr; }
+#define SVR_EXP_VARIANT_BITS 0x1800      /* bit 11: do not wait for brick loads; bit 12: skip the march loop (WRONG pixels) */
+#else
+static inline int  svr_exp_env_int(const char*, int dflt) { return dflt; }
+static inline bool svr_exp_env_set(const char*) { return false; }
+#define SVR_EXP_VARIANT_BITS 0
+#endif
+
 // ---------------------------------------------------------------------------
 // Kernel parameter block.  Passed BY VALUE as the single kernel argument: it
 // lives in the kernarg segment and is read with scalar loads, so every field is
@@ -92,10 +106,10 @@ struct MarchParams {
     int32_t skip_flags;            // empty-space skipping policy bits (1: short march while lanes only follow a maximum; 2: MIP-like
                                    // uniforms — the machine never stops — so a lane that follows a maximum passes blocks that cannot beat it)
     int32_t brick_bytes;           // LDS bytes per wave for brick staging (also what caps the waves per CU: 160 KiB / it)
-    int32_t brick_pow2;            // A/B: round the brick row pitch up to a power of two (the round-1 layout)
+    int32_t brick_pow2;            // -DSVR_EXPERIMENTS builds only: round the brick row pitch up to a power of two (the round-1 layout)
     int32_t block_waves_log2;      // span kernel: block = (1 << this)^2 wave tiles (0: one wave per block)
     const uint32_t* tile_order;    // blockIdx -> tile index (null: contiguous run of tiles per XCD)
-    int32_t dbg_nowait;            // experiments only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
+    int32_t dbg_nowait;            // -DSVR_EXPERIMENTS builds only (WRONG results): bit 0 do not wait for the brick loads, bit 1 skip the march loop
     int32_t brick_lines;           // probe threshold: estimated L1 lookups per wave-load above which bricks are staged
     int32_t orient;                // 1: lane order follows the screen direction of the volume's x axis
     float   xdir[4];               // clip-space image of the data-space direction (1,0,0,0)

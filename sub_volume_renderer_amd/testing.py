@@ -161,6 +161,62 @@ def synthetic_spec(n: int = 64, width: int = 96, height: int = 64, *, inside: bo
 
 
 # ---------------------------------------------------------------------------
+SHARED_PLANES = ("rgba", "depth", "label", "flags", "pick")
+
+
+def planes_identical(a: RenderResult, b: RenderResult) -> dict:
+    """Bit-for-bit equality of every plane two renders of the same frame share (float planes compared as bit
+    patterns, so a NaN equals the same NaN)."""
+    import torch
+
+    out = {}
+    for name in SHARED_PLANES:
+        x, y = getattr(a, name, None), getattr(b, name, None)
+        if x is None or y is None:
+            continue
+        if x.dtype == torch.float32:
+            x, y = x.view(torch.int32), y.view(torch.int32)
+        out[name] = bool(torch.equal(x, y))
+    return out
+
+
+def render_both(volume: SubVolume, camera, width: int, height: int, **kw):
+    """One frame from BOTH instantiations of the march kernel: ``production`` (``count_steps=False``: the code object
+    ``bench.py`` times and every user's draw runs) and ``instrumented`` (``count_steps=True``: the COUNT build that also
+    writes the exact executed-iteration counts).  They are different code objects (register allocation, spills), so
+    a test that only ran the instrumented one would leave the shipped kernel unchecked: this asserts that every
+    plane they share (RGBA, depth, label, flags, pick) is identical bit for bit, and returns
+    ``(production, instrumented)`` for the caller to hold against the oracle."""
+    import torch
+
+    kw.pop("count_steps", None)
+    out = kw.pop("out", None)
+    prod = volume.render(camera, width, height, count_steps=False, **kw)
+    torch.cuda.synchronize()
+    prod = RenderResult(**{k: (None if getattr(prod, k) is None else getattr(prod, k).clone())
+                           for k in ("rgba", "depth", "label", "flags", "steps", "pick")})
+    inst = volume.render(camera, width, height, count_steps=True, out=out, **kw)
+    torch.cuda.synchronize()
+    same = planes_identical(prod, inst)
+    assert same and all(same.values()), f"production (COUNT=false) and instrumented (COUNT=true) kernels disagree: {same}"
+    return prod, inst
+
+
+def hold_both_to(ref, volume: SubVolume, camera, width: int, height: int, *, tol: float = 1e-4, **kw) -> dict:
+    """`render_both`, then BOTH frames against an oracle result `ref`: flags and labels bit-exact, RGBA (relative above
+    1) and depth within `tol` (BASELINE.json north_star: 1e-4), step counts bit-exact for the instrumented kernel.
+    Returns the instrumented kernel's report with the renders under "production" / "instrumented"."""
+    prod, inst = render_both(volume, camera, width, height, **kw)
+    rep = None
+    for which, r in (("production", prod), ("instrumented", inst)):
+        rep = compare(r, ref)
+        assert rep["flags_equal"] and rep["labels_equal"], (which, rep)
+        assert rep["rgba_max_rel"] <= tol and rep["depth_max_abs"] <= tol, (which, rep)
+    assert rep["steps_equal"], rep
+    rep["production"], rep["instrumented"] = prod, inst
+    return rep
+
+
 def compare(res: RenderResult, ref) -> dict:
     """Compare a device render with an oracle result (numpy arrays with the same
     attribute names).  Integer planes must match exactly; float planes are reported

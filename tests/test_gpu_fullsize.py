@@ -20,16 +20,14 @@ GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"
 
 @pytest.mark.parametrize("name", ["demo", "k1", "k2"])
 def test_hip_matches_committed_golden(name):
-    import torch
-
     scene = testing.build(make_golden.specs()[name])
-    r = scene.volume.render(scene.camera, scene.width, scene.height, count_steps=True)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(r.flags.cpu().numpy(), GOLD[f"{name}_flags"])
-    np.testing.assert_array_equal(r.label_numpy(), GOLD[f"{name}_label"])
-    np.testing.assert_array_equal(r.steps.cpu().numpy().view(np.uint32), GOLD[f"{name}_steps"])
-    np.testing.assert_allclose(r.rgba.cpu().numpy(), GOLD[f"{name}_rgba"], rtol=0, atol=1e-4)   # north_star tolerance
-    np.testing.assert_allclose(r.depth.cpu().numpy(), GOLD[f"{name}_depth"], rtol=0, atol=1e-4)
+    prod, inst = testing.render_both(scene.volume, scene.camera, scene.width, scene.height)
+    for r in (prod, inst):                              # the production kernel and the instrumented one
+        np.testing.assert_array_equal(r.flags.cpu().numpy(), GOLD[f"{name}_flags"])
+        np.testing.assert_array_equal(r.label_numpy(), GOLD[f"{name}_label"])
+        np.testing.assert_allclose(r.rgba.cpu().numpy(), GOLD[f"{name}_rgba"], rtol=0, atol=1e-4)   # north_star tolerance
+        np.testing.assert_allclose(r.depth.cpu().numpy(), GOLD[f"{name}_depth"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(inst.steps.cpu().numpy().view(np.uint32), GOLD[f"{name}_steps"])
 
 
 @pytest.fixture(scope="module")
@@ -85,17 +83,16 @@ def test_c2_tiles_stripes_and_variants_equal_full_frame(c2):
     vol, cam, W, H = c2.volume, c2.camera, 1920, 1080
     vol.material.lmip_threshold = 0.5 * 255.0
     N.check(N.lib().svr_set_variant(vol.prepare(), 0), "variant")
-    full = vol.render(cam, W, H, count_steps=True)
-    torch.cuda.synchronize()
+    _, full = testing.render_both(vol, cam, W, H)         # production == instrumented on the whole 1080p frame
     ref = {k: getattr(full, k).clone() for k in ("rgba", "depth", "label", "flags", "steps")}
     assert int((ref["flags"] == 2).sum()) > 100000
-    # 2 x 4 tile grid of BASELINE config 3 (960 x 270 tiles)
+    # 2 x 4 tile grid of BASELINE config 3 (960 x 270 tiles), both kernels
     for ty in range(4):
         for tx in range(2):
-            r = vol.render(cam, W, H, region=FrameRegion.tile(tx * 960, ty * 270, 960, 270), count_steps=True)
-            torch.cuda.synchronize()
-            for k in ref:
-                assert torch.equal(getattr(r, k), ref[k][ty * 270:(ty + 1) * 270, tx * 960:(tx + 1) * 960]), (k, tx, ty)
+            for r in testing.render_both(vol, cam, W, H, region=FrameRegion.tile(tx * 960, ty * 270, 960, 270)):
+                for k in ref:
+                    if getattr(r, k) is not None:
+                        assert torch.equal(getattr(r, k), ref[k][ty * 270:(ty + 1) * 270, tx * 960:(tx + 1) * 960]), (k, tx, ty)
     # interleaved 16-row bands for 8 ranks
     for rank in (0, 3, 7):
         reg = FrameRegion.stripes(W, H, rank, 8, 16)
@@ -109,10 +106,10 @@ def test_c2_tiles_stripes_and_variants_equal_full_frame(c2):
     # (bricks never / always, simple march, tile shape, 2x2-wave workgroups, placement policies)
     for variant in (0x100, 0x200, 0x001, 0x250, 0x002, 0x2000, 0x4000, 0xA202):
         N.check(N.lib().svr_set_variant(vol.prepare(), variant), "variant")
-        r = vol.render(cam, W, H, count_steps=True)
-        torch.cuda.synchronize()
-        for k in ref:
-            assert torch.equal(getattr(r, k), ref[k]), (k, hex(variant))
+        for r in testing.render_both(vol, cam, W, H):
+            for k in ref:
+                if getattr(r, k) is not None:
+                    assert torch.equal(getattr(r, k), ref[k]), (k, hex(variant))
     N.check(N.lib().svr_set_variant(vol.prepare(), 0), "variant")
 
 
@@ -135,11 +132,7 @@ def test_c2_oracle_parity_on_sampled_rows(c2, mode):
     m = dict(c2.spec.material)
     m["lmip_threshold"] = thr
     ref = lmip.render(rings, c2.spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), m, W, H, region=sample)
-    res = vol.render(cam, W, H, region=sample, count_steps=True)
-    torch.cuda.synchronize()
-    rep = testing.compare(res, ref)
-    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
-    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    rep = testing.hold_both_to(ref, vol, cam, W, H, region=sample)     # production and instrumented kernels
     assert rep["total_steps"] > 30_000_000
 
 
@@ -180,12 +173,8 @@ def test_config1_literal_multi_scale_script_480x480():
 
     scene = testing.build(testing.multiscale_demo_spec(480, 480, tiles=16))
     assert [tuple(d.shape) for d, _ in scene.spec.pairs] == [(256, 256, 768), (128, 128, 768), (64, 64, 768)]
-    res = scene.volume.render(scene.camera, 480, 480, count_steps=True)
-    torch.cuda.synchronize()
     ref = lmip.render_scene(scene)
-    rep = testing.compare(res, ref)
-    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
-    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    rep = testing.hold_both_to(ref, scene.volume, scene.camera, 480, 480)      # production and instrumented kernels
     assert set(np.unique(ref.label[ref.flags == 2])) == {0, 1, 2} and rep["n_hit"] > 10000
 
 
@@ -256,17 +245,16 @@ def test_c5_config3_tiles_equal_full_frame(c5):
 
     vol, cam, W, H = c5.volume, c5.camera, 1920, 1080
     vol.material.lmip_threshold = 0.3 * 255.0
-    full = vol.render(cam, W, H, count_steps=True)
-    torch.cuda.synchronize()
+    _, full = testing.render_both(vol, cam, W, H)
     ref = {k: getattr(full, k).clone() for k in ("rgba", "depth", "label", "flags", "steps")}
     assert int((ref["flags"] == 2).sum()) > 100000
     assert len(torch.unique(ref["label"][ref["flags"] == 2])) > 1000       # many distinct labels reach the screen
     for ty in range(4):
         for tx in range(2):
-            r = vol.render(cam, W, H, region=FrameRegion.tile(tx * 960, ty * 270, 960, 270), count_steps=True)
-            torch.cuda.synchronize()
-            for k in ref:
-                assert torch.equal(getattr(r, k), ref[k][ty * 270:(ty + 1) * 270, tx * 960:(tx + 1) * 960]), (k, tx, ty)
+            for r in testing.render_both(vol, cam, W, H, region=FrameRegion.tile(tx * 960, ty * 270, 960, 270)):
+                for k in ref:
+                    if getattr(r, k) is not None:
+                        assert torch.equal(getattr(r, k), ref[k][ty * 270:(ty + 1) * 270, tx * 960:(tx + 1) * 960]), (k, tx, ty)
 
 
 @pytest.mark.parametrize("mode", ["lmip", "full"])
@@ -284,11 +272,7 @@ def test_c5_oracle_parity_on_sampled_rows(c5, mode):
     m = dict(c5.spec.material)
     m["lmip_threshold"] = thr
     ref = lmip.render(c5.rings, c5.spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), m, W, H, region=sample)
-    res = vol.render(cam, W, H, region=sample, count_steps=True)
-    torch.cuda.synchronize()
-    rep = testing.compare(res, ref)
-    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
-    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    rep = testing.hold_both_to(ref, vol, cam, W, H, region=sample)     # production and instrumented kernels
     assert rep["total_steps"] > 30_000_000
     if mode == "full":
         del c5.__dict__["rings"]
@@ -356,10 +340,6 @@ def test_c4_4096_streamed_flythrough_rings_and_pixels_match_oracle():
                           scale=tuple(float(v) for v in u["scale_factor"])))
     sample = FrameRegion(0, 0, W, 27, 1, 40)
     cam = spec.camera()
-    res = vol.render(cam, W, H, region=sample, count_steps=True)
-    torch.cuda.synchronize()
     ref = lmip.render(rings, spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), spec.material, W, H, region=sample)
-    rep = testing.compare(res, ref)
-    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], rep
-    assert rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4, rep
+    rep = testing.hold_both_to(ref, vol, cam, W, H, region=sample)     # production and instrumented kernels
     assert rep["n_hit"] > 1000 and frames == 40

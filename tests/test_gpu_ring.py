@@ -57,6 +57,8 @@ def test_boundary_known_answers(case):
     for r in case["loads"]:
         buf.load_logical_roi(roi_of(r))
         orac.load_logical_roi(as_pair(r))
+        if case.get("not_none_after_each_load"):
+            assert buf._current_logical_roi_in_pixels is not None
     got = buf._current_logical_roi_in_pixels
     got = None if got is None else (tuple(got.offset), tuple(got.shape))
     assert got == orac.current_logical_roi_in_pixels

@@ -28,9 +28,12 @@ def _roi_pair(r):
 
 
 def _assert_frame(res, ref, what):
-    rep = testing.compare(res, ref)
-    assert rep["flags_equal"] and rep["labels_equal"] and rep["steps_equal"], (what, rep)
-    assert rep["rgba_max_rel"] <= RGBA_TOL and rep["depth_max_abs"] <= 1e-4, (what, rep)
+    """`res`: one render, or the (production, instrumented) pair of `testing.render_both`."""
+    for r in (res if isinstance(res, tuple) else (res,)):
+        rep = testing.compare(r, ref)
+        assert rep["flags_equal"] and rep["labels_equal"] and rep.get("steps_equal", True), (what, rep)
+        assert ("steps_equal" in rep) == (r.steps is not None)
+        assert rep["rgba_max_rel"] <= RGBA_TOL and rep["depth_max_abs"] <= 1e-4, (what, rep)
 
 
 def test_frames_in_flight_on_two_streams_never_tear_under_async_reloads():
@@ -48,7 +51,8 @@ def test_frames_in_flight_on_two_streams_never_tear_under_async_reloads():
     d = np.array(spec.cam_target) - eye
     d = d / np.linalg.norm(d)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs = [vol._outputs(spec.height, spec.width, True), None]
+    # stream 0 carries the PRODUCTION kernel (no step plane), stream 1 the instrumented one
+    outs = [vol._outputs(spec.height, spec.width, False), None]
     vol._out_cache = {}
     outs[1] = vol._outputs(spec.height, spec.width, True)
     pending = []
@@ -64,7 +68,7 @@ def test_frames_in_flight_on_two_streams_never_tear_under_async_reloads():
             ref = lmip.render(rings, mats, orac.volume_dimensions_shader, spec.material, spec.width, spec.height)
             _assert_frame(res, ref, ("frame", k - 2))
         with torch.cuda.stream(streams[slot]):
-            res = vol.render(cam, spec.width, spec.height, count_steps=True, out=outs[slot])
+            res = vol.render(cam, spec.width, spec.height, count_steps=bool(slot), out=outs[slot])
         # what this frame must show: the textures BEFORE the next move, the ROIs published at its prepare()
         rings = [dict(r, density=r["density"].copy(), labels=r["labels"].copy()) for r in _published_rings(vol, orac)]
         pending.append((res, rings, spec.matrices(), streams[slot]))
@@ -124,8 +128,7 @@ def test_failed_asynchronous_load_keeps_the_shrunk_window_and_recovers():
     assert shrunk is None or before[0].contains(shrunk)
     assert vol.poll_uploads(wait=True) is True                # raised once, nothing left in flight
     # the frame still equals the oracle for the published state: old textures where the shrunk window maps them
-    res = vol.render(scene.camera, spec.width, spec.height, count_steps=True)
-    torch.cuda.synchronize()
+    res = testing.render_both(vol, scene.camera, spec.width, spec.height)
     rings = _published_rings(vol, orac)                       # oracle textures = before the move
     if shrunk is not None:
         _assert_frame(res, lmip.render(rings, spec.matrices(), orac.volume_dimensions_shader, plain.material,
@@ -296,8 +299,7 @@ def test_rings_beyond_the_span_kernels_24_bit_row_index_render_exactly():
     spec.cam_position = tuple(c + np.array([-90.0, 40.0, 55.0]))
     spec.cam_target = tuple(c)
     scene = testing.build(spec)
-    res = scene.volume.render(scene.camera, spec.width, spec.height, count_steps=True)
-    torch.cuda.synchronize()
+    res = testing.render_both(scene.volume, scene.camera, spec.width, spec.height)
     # the oracle would need the 2 GiB ring as f32: feed it an equivalent small ring instead (same ROI, the
     # window does not wrap, so slot == voxel index in both)
     small = testing.synthetic_spec(64, 96, 64, pairs=[(data, seg)], chunk_shapes=[(8, 8, 64)], ring_shapes=[(6, 5, 1)],
@@ -342,8 +344,7 @@ def test_zarr_v3_sharded_store_as_backing_data(tmp_path):
         scene.volume.center_on_position(tuple(p), asynchronous=bool(k & 1))
         scene.volume.poll_uploads(wait=True)
         orac.center_on_position(tuple(p))
-        res = scene.volume.render(spec.camera(), spec.width, spec.height, count_steps=True)
-        torch.cuda.synchronize()
+        res = testing.render_both(scene.volume, spec.camera(), spec.width, spec.height)
         ref = lmip.render(lmip.rings_of(orac), spec.matrices(), orac.volume_dimensions_shader, spec.material, spec.width, spec.height)
         _assert_frame(res, ref, ("zarr", k))
     for b, ob in zip(scene.volume.wrapping_buffers, orac.wrapping_buffers):
@@ -371,8 +372,7 @@ def test_rings_of_4_gib_in_total_keep_the_span_kernel_with_one_resource_per_lod(
     spec.centers = [((31.5, 31.5, 31.5), [(32, 32, 32), (32, 32, 32)])]       # LOD 0 only in the middle: LOD transitions
     scene = testing.build(spec)
     assert scene.volume._rings.density_storage == "uint16"
-    res = scene.volume.render(scene.camera, spec.width, spec.height, count_steps=True)
-    torch.cuda.synchronize()
+    res = testing.render_both(scene.volume, scene.camera, spec.width, spec.height)
     census = (C.c_uint32 * 8)()
     N.check(N.lib().svr_debug_counters(scene.volume._rings.handle, census, 1), "svr_debug_counters")
     assert census[6] > 0 and census[0] > 0                  # the SPAN kernel ran (the simple one keeps no census), general batches too
@@ -384,8 +384,7 @@ def test_rings_of_4_gib_in_total_keep_the_span_kernel_with_one_resource_per_lod(
     for mode in ("mip",):
         scene.volume.material.render_mode = mode
         small.material = dict(small.material, render_mode=mode)
-        res = scene.volume.render(scene.camera, spec.width, spec.height, count_steps=True)
-        torch.cuda.synchronize()
+        res = testing.render_both(scene.volume, scene.camera, spec.width, spec.height)
         _assert_frame(res, lmip.render_spec(small), "big rings, mip")
 
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+# C2 on float32 rings (the reference's layout), full mode: slab length x LDS bytes per wave.
+# prints: ms per step (4 frames in flight), one frame at a time, kernel alone
+# (needs a library built with -DSVR_EXPERIMENTS: the knobs are compiled out of the shipped one)
+for cfg in "SVR_NOP=1" "SVR_SLAB_SHIFT=1" "SVR_SLAB_SHIFT=2" "SVR_BRICK_BYTES=12288" "SVR_SLAB_SHIFT=1 SVR_BRICK_BYTES=12288" "SVR_BRICK_BYTES=16384" "SVR_SLAB_SHIFT=1 SVR_BRICK_BYTES=16384" "SVR_BRICK_BYTES=10240"; do
+  echo "== $cfg"
+  env $cfg python bench.py --ring-storage float32 --modes full --no-cpu-baseline --repeats 2 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['sequential']['median_ms'], d['roofline']['kernel_ms'])"
+done

@@ -3,7 +3,10 @@
 and ring shapes, anisotropic, u8 / u16 / f32 rings, with or without segmentation), ring windows, cameras (outside /
 inside / grazing), materials (LMIP, MIP and weighted average, clipping planes), frame sizes, frame regions and kernel variants
 (empty-space skipping on and off, bricks always / never / by probe, tile shapes, placements).  Integer planes must be identical, float planes within 1e-4.
-usage: fuzz_parity.py [cases] [first_seed] [brick]      (prints one line per failing case, then a summary)"""
+Every case runs BOTH instantiations of the march (`production`: count_steps off, the code object bench.py times;
+`instrumented`: the COUNT build with exact step counts) unless `kernel=` names one.
+usage: fuzz_parity.py [cases] [first_seed] [brick] [kernel=both|production|instrumented]
+(prints one line per failing case, then a summary)"""
 import os
 import sys
 
@@ -135,7 +138,10 @@ def main():
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    brick = len(sys.argv) > 3 and sys.argv[3] == "brick"
+    brick = "brick" in sys.argv[3:]
+    kernel = ([a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("kernel=")] or ["both"])[0]
+    assert kernel in ("both", "production", "instrumented"), kernel
+    runs = {"both": (False, True), "production": (False,), "instrumented": (True,)}[kernel]
     bricks = 0
     bad = skipped = hits = 0
     for seed in range(first, first + cases):
@@ -157,21 +163,26 @@ def main():
         import ctypes as C
         dbg = (C.c_uint32 * 8)()
         N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
-        res = scene.volume.render(scene.camera, scene.width, scene.height, region=region, count_steps=True, pick=True)
-        torch.cuda.synchronize()
-        N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
-        bricks += dbg[2] > 0
         ref = lmip.render_spec(spec, region=region, vol=ovol, pick_id=scene.volume.id)
-        rep = testing.compare(res, ref)
-        pick_ok = bool(np.array_equal(res.pick.cpu().numpy().view(np.uint64), ref.pick))
-        ok = (rep["flags_equal"] and rep["labels_equal"] and rep.get("steps_equal", True) and pick_ok
-              and rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4)
+        ok = True
+        for counted in runs:
+            res = scene.volume.render(scene.camera, scene.width, scene.height, region=region, count_steps=counted, pick=True)
+            torch.cuda.synchronize()
+            if counted:
+                N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
+                bricks += dbg[2] > 0
+            rep = testing.compare(res, ref)
+            pick_ok = bool(np.array_equal(res.pick.cpu().numpy().view(np.uint64), ref.pick))
+            this_ok = (rep["flags_equal"] and rep["labels_equal"] and rep.get("steps_equal", True) and pick_ok
+                       and rep["rgba_max_rel"] <= 1e-4 and rep["depth_max_abs"] <= 1e-4)
+            if not this_ok:
+                print(f"seed {seed}: MISMATCH kernel={'instrumented' if counted else 'production'} variant={variant:#x} "
+                      f"region={region} pick_ok={pick_ok} {rep}", flush=True)
+            ok = ok and this_ok
         hits += rep["n_hit"] > 0
-        if not ok:
-            bad += 1
-            print(f"seed {seed}: MISMATCH variant={variant:#x} region={region} pick_ok={pick_ok} {rep}", flush=True)
+        bad += not ok
         del scene
-    print(f"fuzz{' (brick-biased)' if brick else ''}: {cases} cases from seed {first}: {bad} mismatching, {skipped} rejected by both, "
+    print(f"fuzz{' (brick-biased)' if brick else ''} kernel={kernel}: {cases} cases from seed {first}: {bad} mismatching, {skipped} rejected by both, "
           f"{hits} with hits, {bricks} staged LDS bricks", flush=True)
     sys.exit(1 if bad else 0)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over a minimal render driver (tools/prof_driver.py): one counter group per pass, never
 # combined with trace domains, FETCH_SIZE / WRITE_SIZE in passes of their own (MI355X_MICROARCH.md).
-# usage: tools/pmc.sh <tag> [groups] [mode] [n] [variant] [camera]
+# usage: [PROF_EXTRA='--config C5 --ring-storage float32'] tools/pmc.sh <tag> [groups] [mode] [n] [variant] [camera]
 #   groups: comma list of  trace,sq,sq2,lds,tcp,tcp2,ta,tcc,fetch,write,grbm   (default: trace,sq,lds,tcc,fetch,write)
 set -o pipefail
 TAG=${1:-r02}; GROUPS_=${2:-trace,sq,lds,tcc,fetch,write}; MODE=${3:-full}; NVOL=${4:-1024}; VAR=${5:-0}; CAM=${6:-K1}
@@ -21,7 +21,7 @@ declare -A SETS=(
 )
 for G in ${GROUPS_//,/ }; do
   if [ "$G" = trace ]; then FLAGS="--kernel-trace --stats"; else FLAGS="--pmc ${SETS[$G]}"; fi
-  timeout -k 10 240 rocprofv3 $FLAGS --kernel-include-regex march --output-format csv -d $OUT/$G -- python3 $ROOT/tools/prof_driver.py $MODE $NVOL 5 $VAR $CAM > $OUT/$G.log 2>&1 \
+  timeout -k 10 240 rocprofv3 $FLAGS --kernel-include-regex march --output-format csv -d $OUT/$G -- python3 $ROOT/tools/prof_driver.py $MODE $NVOL 5 $VAR $CAM $PROF_EXTRA > $OUT/$G.log 2>&1 \
     || { echo "pass $G failed"; tail -5 $OUT/$G.log; exit 1; }
 done
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
