@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0      # PCIe Gen5 x16 spec (same guide, chip-level parameters)
-PROFILE_ROUND = "r02"     # profiles/<round>/traffic.json: PMC-derived HBM bytes of the default workload
+PROFILE_ROUND = "r03"     # profiles/<round>/traffic.json: PMC-derived figures of the default workloads (one entry per ring storage)
 
 
 def parse():
@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
                     help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
+    ap.add_argument("--no-float32-block", action="store_true",
+                    help="C2 / C5 at N = 1 with native rings: skip the second measurement of the same workload on float32 rings "
+                         "(the reference's own layout, _wrapping_buffer.py:50-53), reported as `float32_rings`")
     ap.add_argument("--source-dtype", choices=["uint8", "uint16"], default="uint8",
                     help="C2 / C5: dtype of the density arrays handed to SubVolume (uint16: values x 257, threshold and clim "
                          "scaled alike -> uint16 rings)")
@@ -257,24 +260,99 @@ def main():
     modes = [m for m in args.modes.split(",") if m]
     assert "full" in modes, "--modes must include full (the headline number)"
     lmip_threshold = float(spec.material["lmip_threshold"])
-
-    def set_mode(full):
-        vol.material.lmip_threshold = float("inf") if full else lmip_threshold
-
-    def instrumented(camera_obj):
-        r = vol.render(camera_obj, W, H, region=full_frame, count_steps=True)
-        torch.cuda.synchronize()
-        return dict(steps=int(r.steps.to(torch.int64).sum().item()), hits=int((r.flags == 2).sum().item()),
-                    frags=int((r.flags != 0).sum().item()))
-
     want_all = args.planes == "all"
+
+    class Harness:
+        """The timing loops bound to ONE volume (the default line measures two: native rings and float32 rings)."""
+
+        def __init__(self, vol):
+            self.vol = vol
+            self.handle = vol._rings.handle
+
+        def set_mode(self, full):
+            self.vol.material.lmip_threshold = float("inf") if full else lmip_threshold
+
+        def set_variant(self, v):
+            N.check(N.lib().svr_set_variant(self.handle, v), "svr_set_variant")
+
+        def instrumented(self, camera_obj):
+            r = self.vol.render(camera_obj, W, H, region=full_frame, count_steps=True)
+            torch.cuda.synchronize()
+            return dict(steps=int(r.steps.to(torch.int64).sum().item()), hits=int((r.flags == 2).sum().item()),
+                        frags=int((r.flags != 0).sum().item()))
+
+        def loop(self, F, prime_s=0.0):
+            return FrameLoop(self, F, prime_s)
+
+        def timed(self, loop, mode, nframes, warmup):
+            """W untimed frames, then EXACTLY nframes bracketed by barrier + synchronize; max over ranks."""
+            self.set_mode(mode == "full")
+            # block -> tile placement: with several frames in flight the next frame's head fills this frame's tail anyway,
+            # and the camera-independent table (policy 7) is ~1 % faster; one frame at a time wants the cost-sorted one
+            # (policy 0, the library's default).  An explicit --variant placement is left alone.
+            placement = (7 << 13) if (loop.F > 1 and not (args.variant >> 13) & 7) else 0
+            self.set_variant(args.variant | placement)
+            for _ in range(warmup):
+                loop.frame()
+            loop.drain()
+            if collective:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(nframes):
+                loop.frame()
+            loop.drain()                                     # the K-th frame's gather + un-tile are inside the timed region
+            torch.cuda.synchronize()
+            if collective:
+                dist.barrier()
+            dt = time.perf_counter() - t
+            if collective:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
+
+        def kernel_ms(self, mode, out, iters=10):
+            """The dominant kernel alone: HIP events on the stream the kernel runs on (svr_time_render)."""
+            self.set_mode(mode == "full")
+            self.set_variant(args.variant)
+            self.vol.prepare()
+            cb, fb = self.vol.camera_block(cam), self.vol.frame_block(W, H, region)
+            ob = N.Outputs()
+            ob.rgba, ob.depth, ob.label, ob.flags, ob.steps = (out.rgba.data_ptr(), out.depth.data_ptr(),
+                                                               out.label.data_ptr(), out.flags.data_ptr(), None)
+            ms = C.c_float(0)
+            N.check(N.lib().svr_time_render(self.handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)),
+                    "svr_time_render")
+            return float(ms.value)
+
+        def measure(self, in_flight, prime_s):
+            """Exact step / hit / pixel counts (instrumented kernel, untimed), the contract's K-step region (+ repeats,
+            + one frame at a time) per mode, and the kernel alone."""
+            counts = {}
+            for mode in modes:
+                self.set_mode(mode == "full")
+                counts[mode] = self.instrumented(cam)
+            loop = self.loop(max(1, in_flight), prime_s=prime_s)
+            seq = loop if loop.F == 1 else self.loop(1)
+            dts = {}
+            for mode in modes:
+                first = self.timed(loop, mode, steps, args.warmup)                       # the contract's K steps
+                more = [self.timed(loop, mode, steps, 0) for _ in range(max(0, args.repeats - 1))]
+                one = [self.timed(seq, mode, steps, 1 if i == 0 else 0) for i in range(max(1, args.repeats))]
+                dts[mode] = (first, [first] + more, one)
+            torch.cuda.synchronize()
+            kms = {mode: sorted(self.kernel_ms(mode, loop.outs[0]) for _ in range(3))[1] for mode in modes}   # median of 3 x 10 launches
+            return dict(counts=counts, dts=dts, kms=kms, loop=loop,
+                        es={"uint8": 1, "uint16": 2}.get(self.vol._rings.density_storage, 4))
 
     # ---- frames in flight: frame k runs on stream k % F with its own output buffers; on N > 1 each stream
     # carries render -> gather -> un-tile of its frames, so frame k's collective and its tail of long rays overlap
     # frame k+1's march.
     class FrameLoop:
-        def __init__(self, F, prime_s=0.0):
-            self.F = F
+        def __init__(self, h, F, prime_s=0.0):
+            self.h, self.F = h, F
+            vol = h.vol
             self.outs = []
             for _ in range(F):
                 vol._out_cache = {}
@@ -286,7 +364,7 @@ def main():
             # per-stream resources of the library (placement table + its pinned staging buffer, render marks) are
             # created at a stream's first render: do that here, during setup (a short warm-up never reaches the 4th
             # stream); `prime_s` seconds of untimed frames on top let the GPU's clocks ramp up before the W warm-up frames
-            set_mode(True)
+            h.set_mode(True)
             t_end = time.perf_counter() + prime_s
             i = 0
             while i < 2 * F or time.perf_counter() < t_end:
@@ -301,6 +379,7 @@ def main():
             return (res.rgba, res.depth, res.label) if want_all else res.rgba
 
         def frame(self, camera_obj=None):
+            vol = self.h.vol
             slot = self.k % self.F
             self.k += 1
             with torch.cuda.stream(self.streams[slot]):
@@ -325,89 +404,110 @@ def main():
                             if f is not None:
                                 self.last = f
 
-    def timed(loop, mode, nframes, warmup):
-        """W untimed frames, then EXACTLY nframes bracketed by barrier + synchronize; max over ranks."""
-        set_mode(mode == "full")
-        # block -> tile placement: with several frames in flight the next frame's head fills this frame's tail anyway,
-        # and the camera-independent table (policy 7) is ~1 % faster; one frame at a time wants the cost-sorted one
-        # (policy 0, the library's default).  An explicit --variant placement is left alone.
-        placement = (7 << 13) if (loop.F > 1 and not (args.variant >> 13) & 7) else 0
-        N.check(N.lib().svr_set_variant(handle, args.variant | placement), "svr_set_variant")
-        for _ in range(warmup):
-            loop.frame()
-        loop.drain()
-        if collective:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(nframes):
-            loop.frame()
-        loop.drain()                                     # the K-th frame's gather + un-tile are inside the timed region
-        torch.cuda.synchronize()
-        if collective:
-            dist.barrier()
-        dt = time.perf_counter() - t
-        if collective:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
+    harness = Harness(vol)
+    set_mode, instrumented = harness.set_mode, harness.instrumented
+
+    def algo_bytes(c, npix):
+        # 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
+        # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
+        return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
+
+    def pmc_entry(ring_storage):
+        """The PMC-derived figures of THIS workload on THIS kernel (profiles/<round>/traffic.json, written by
+        tools/profile_bench.sh: rocprofv3 cannot run from inside the process it profiles), or a note why there are none."""
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
+        here = dict(config=cfg, n=n, width=W, height=H, camera=camera, variant=args.variant,
+                    ring_storage=ring_storage, kernel_source_sha16=kernel_source_hash())
+        if not os.path.exists(tpath):
+            return None, None
+        with open(tpath) as f:
+            tj = json.load(f)
+        for e in tj.get("entries", [tj]):
+            if all(e.get("workload", {}).get(k) == v for k, v in here.items()):
+                return e, {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "command": e.get("command"),
+                           "kernel_source_sha16": e["workload"]["kernel_source_sha16"]}
+        return None, {"file": f"profiles/{PROFILE_ROUND}/traffic.json",
+                      "stale": "taken on another kernel build or workload: not carried over"}
+
+    def roofline_block(m, ring_storage, npix):
+        """SURVEY.md 8d's figure for the dominant kernel, and beside it what the counters say binds it."""
+        c, k_ms, es = m["counts"]["full"], m["kms"]["full"], m["es"]
+        a_full = algo_bytes(c, npix) / (k_ms * 1e-3) / 1e9
+        nb = es * c["steps"] + 4 * c["hits"] + 25 * npix               # what the ring's element type really needs
+        entry, source = pmc_entry(ring_storage)
+        traffic = entry["traffic_bytes_per_launch"] if entry else None
+        block = {
+            "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": a_full / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+            "frac_is": "algorithmic-bytes throughput by SURVEY.md 8d's definition (4 B charged per ray-step, the reference's "
+                       "r32float texel) over the HBM peak: how the march compares with a texture-unit implementation on the "
+                       "reference's layout, NOT the share of HBM bandwidth in use (that is traffic_frac)",
+            "kernel": "march_span (full mode)", "kernel_ms": k_ms,
+            "algorithmic_bytes": algo_bytes(c, npix),
+            "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
+            "native_layout": {"bytes": nb, "achieved": nb / (k_ms * 1e-3) / 1e9, "frac": nb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": f"{es} B/ray-step: what the {ring_storage} rings really need"},
+        }
+        if traffic:
+            block["traffic_frac"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if entry and entry.get("binding"):
+            block["binding"] = entry["binding"]                          # the resource the counters show busiest
+        return block
+
+    def result_blocks(m, ring_storage, with_roofline):
+        """`value` & co. of one measured volume (top level of the line for the native rings, `float32_rings` block beside)."""
+        counts, dts = m["counts"], m["dts"]
+        first, rep, one = dts["full"]
+        blk = {
+            "value": counts["full"]["steps"] / (first / steps) / 1e6, "unit": "Mray-steps/s",
+            "frames_per_s": steps / first, "ms_per_step": first / steps * 1e3,
+            # the same K-step region repeated, and with ONE frame at a time (no overlap of tails and heads):
+            # per-frame kernel time <= sequential ms_per_step must hold inside this record
+            "spread": dict(summarise([d / steps * 1e3 for d in rep]), what=f"ms per step over repeats of the {steps}-step region, {m['loop'].F} frames in flight"),
+            "sequential": dict(summarise([d / steps * 1e3 for d in one]), frames_in_flight=1,
+                               value=counts["full"]["steps"] / (float(np.median(one)) / steps) / 1e6),
+        }
+        if "lmip" in dts:
+            lf, lrep, lone = dts["lmip"]
+            blk["lmip"] = {
+                "march_mode": f"lmip threshold={lmip_threshold:g} fall_off=0.5 max_samples=10",
+                "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
+                "value": counts["lmip"]["steps"] / (lf / steps) / 1e6, "unit": "Mray-steps/s",
+                "value_is": "executed iterations of raycast.wgsl:29-62 per second (what the reference's loop would run): "
+                            "empty-space skipping executes most of them without fetching a texel",
+                "frames_per_s": steps / lf, "ms_per_step": lf / steps * 1e3,
+                "spread": summarise([d / steps * 1e3 for d in lrep]),
+                "sequential": dict(summarise([d / steps * 1e3 for d in lone]), frames_in_flight=1),
+            }
+        if with_roofline:
+            npix = W * H
+            blk["roofline"] = roofline_block(m, ring_storage, npix)
+            if "lmip" in m["kms"]:
+                a_lmip = algo_bytes(counts["lmip"], npix) / (m["kms"]["lmip"] * 1e-3) / 1e9
+                # NOT a roofline fraction: skipped iterations are charged 4 B each without moving a byte
+                blk["lmip"]["kernel"] = {"kernel_ms": m["kms"]["lmip"], "ref_equiv_GBps": a_lmip,
+                                         "ref_equiv_frac": a_lmip / HBM_PEAK_GBS,
+                                         "note": "reference-equivalent bytes (4 B per executed iteration, SURVEY.md 8d) per second "
+                                                 "over the HBM peak; the kernel skips most iterations without a fetch, so this is no "
+                                                 "measure of memory use and can exceed 1: compare kernel_ms"}
+        return blk
 
     result = None
     if cfg != "C4":
-        # ---- exact step / hit / pixel counts of the whole frame (instrumented kernel, untimed)
-        counts = {}
-        for mode in modes:
-            set_mode(mode == "full")
-            counts[mode] = instrumented(cam)
-        loop = FrameLoop(max(1, args.in_flight), prime_s=args.prime_s)
-        seq = loop if loop.F == 1 else FrameLoop(1)
-        dts = {}
-        for mode in modes:
-            first = timed(loop, mode, steps, args.warmup)                       # the contract's K steps
-            more = [timed(loop, mode, steps, 0) for _ in range(max(0, args.repeats - 1))]
-            one = [timed(seq, mode, steps, 1 if i == 0 else 0) for i in range(max(1, args.repeats))]
-            dts[mode] = (first, [first] + more, one)
-        out = loop.outs[0]
-
-        # ---- roofline of the dominant kernel: HIP events on the stream the kernel runs on
-        def kernel_ms(mode, iters=10):
-            set_mode(mode == "full")
-            N.check(N.lib().svr_set_variant(handle, args.variant), "svr_set_variant")
-            vol.prepare()
-            cb, fb = vol.camera_block(cam), vol.frame_block(W, H, region)
-            ob = N.Outputs()
-            ob.rgba, ob.depth, ob.label, ob.flags, ob.steps = (out.rgba.data_ptr(), out.depth.data_ptr(),
-                                                               out.label.data_ptr(), out.flags.data_ptr(), None)
-            ms = C.c_float(0)
-            N.check(N.lib().svr_time_render(handle, C.byref(cb), C.byref(fb), C.byref(ob), iters, C.byref(ms)),
-                    "svr_time_render")
-            return float(ms.value)
-
-        torch.cuda.synchronize()
-        kms = {mode: sorted(kernel_ms(mode) for _ in range(3))[1] for mode in modes}     # median of 3 x 10 launches
-        es = {"uint8": 1, "uint16": 2}.get(vol._rings.density_storage, 4)
-
-        def algo_bytes(c, npix):
-            # SURVEY.md §8d: 4 B per ray-step (r32float texel) + 4 B per hit ray (r32uint label)
-            # + per written pixel: 16 B RGBA + 4 B depth + 4 B label + 1 B flags
-            return 4 * c["steps"] + 4 * c["hits"] + 25 * npix
-
-        def native_bytes(c, npix):
-            return es * c["steps"] + 4 * c["hits"] + 25 * npix        # what the ring's element type really needs
-
+        m = harness.measure(args.in_flight, args.prime_s)
+        counts, loop = m["counts"], m["loop"]
         if rank == 0:
-            first, rep, one = dts["full"]
             dens = "u8" if args.source_dtype == "uint8" else "u16"
             workload = {"C2": f"C2: {n}^3 {dens} density + u32 labels, 3 LODs",
                         "C5": f"C5: {n}^3 {dens} density + u32 labels ({n_labels} labels), 3 LODs, 256 hues, fog 0.05, threshold 0.3 of the range"}[cfg]
+            blk = result_blocks(m, vol._rings.density_storage, world == 1)
             result = {
                 "metric": "Mray-steps/sec (+ frames/sec) of the LMIP sub-volume march at 1920x1080, 3-LOD 1024^3 volume",
-                "value": counts["full"]["steps"] / (first / steps) / 1e6,
+                "value": blk["value"],
                 "unit": "Mray-steps/s",
-                "frames_per_s": steps / first,
+                "frames_per_s": blk["frames_per_s"],
                 "n_gpus": world, "steps": steps, "warmup": args.warmup,
-                "ms_per_step": first / steps * 1e3,
+                "ms_per_step": blk["ms_per_step"],
                 "higher_is_better": True,
                 "scaling": "strong",
                 "vs_baseline": None,
@@ -430,63 +530,33 @@ def main():
                                  if (loop.F > 1 and not (args.variant >> 13) & 7) else "as --variant says (0: cost-sorted per camera)",
                     "ring_storage": vol._rings.density_storage,
                 },
-                # the same K-step region repeated, and with ONE frame at a time (no overlap of tails and heads):
-                # per-frame kernel time <= sequential ms_per_step must hold inside this record
-                "spread": dict(summarise([d / steps * 1e3 for d in rep]), what=f"ms per step over repeats of the {steps}-step region, {loop.F} frames in flight"),
-                "sequential": dict(summarise([d / steps * 1e3 for d in one]), frames_in_flight=1,
-                                   value=counts["full"]["steps"] / (float(np.median(one)) / steps) / 1e6),
             }
-            if "lmip" in dts:
-                lf, lrep, lone = dts["lmip"]
-                result["lmip"] = {
-                    "march_mode": f"lmip threshold={lmip_threshold:g} fall_off=0.5 max_samples=10",
-                    "ray_steps_per_frame": counts["lmip"]["steps"], "hit_rays": counts["lmip"]["hits"],
-                    "value": counts["lmip"]["steps"] / (lf / steps) / 1e6, "unit": "Mray-steps/s",
-                    "frames_per_s": steps / lf, "ms_per_step": lf / steps * 1e3,
-                    "spread": summarise([d / steps * 1e3 for d in lrep]),
-                    "sequential": dict(summarise([d / steps * 1e3 for d in lone]), frames_in_flight=1),
-                }
+            for k in ("spread", "sequential", "lmip", "roofline"):
+                if k in blk:
+                    result[k] = blk[k]
             result["setup_s"] = {"synthesize": round(t_gen, 2), "ring_upload": round(t_load, 2)}
-            if world == 1:
-                npix = W * H
-                a_full = algo_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9
-                # HBM bytes per launch from the PMC passes of this same command (rocprofv3 cannot run from inside
-                # the process it profiles): written by tools/profile_bench.sh, valid only for the kernel and the
-                # workload it was taken on
-                traffic, traffic_source = None, None
-                tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
-                here = dict(config=cfg, n=n, width=W, height=H, camera=camera, variant=args.variant,
-                            ring_storage=vol._rings.density_storage, kernel_source_sha16=kernel_source_hash())
-                if os.path.exists(tpath):
-                    with open(tpath) as f:
-                        tj = json.load(f)
-                    if all(tj.get("workload", {}).get(k) == v for k, v in here.items()):
-                        traffic = tj["traffic_bytes_per_launch"]
-                        traffic_source = {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "command": tj.get("command"),
-                                          "kernel_source_sha16": tj["workload"]["kernel_source_sha16"]}
-                    else:
-                        traffic_source = {"file": f"profiles/{PROFILE_ROUND}/traffic.json",
-                                          "stale": "taken on another kernel build or workload: not carried over"}
-                result["roofline"] = {
-                    "bound": "hbm", "achieved": a_full, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": a_full / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": "march_span (full mode)", "kernel_ms": kms["full"],
-                    "algorithmic_bytes": algo_bytes(counts["full"], npix),
-                    "algorithmic_bytes_def": "4 B/ray-step (reference r32float texel) + 4 B/hit + 25 B/pixel (SURVEY.md 8d)",
-                    "native_layout": {"bytes": native_bytes(counts["full"], npix),
-                                      "achieved": native_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9,
-                                      "frac": native_bytes(counts["full"], npix) / (kms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                      "note": f"{es} B/ray-step: what the {vol._rings.density_storage} rings really need"},
-                }
-                if traffic:
-                    result["roofline"]["traffic_frac"] = traffic / (kms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                if "lmip" in kms:
-                    a_lmip = algo_bytes(counts["lmip"], npix) / (kms["lmip"] * 1e-3) / 1e9
-                    result["lmip"]["roofline"] = {"achieved": a_lmip, "frac": a_lmip / HBM_PEAK_GBS, "kernel_ms": kms["lmip"]}
-                    if a_lmip > HBM_PEAK_GBS:
-                        result["lmip"]["roofline"]["note"] = (
-                            "above 1: SURVEY.md 8d charges 4 B for every executed iteration, and empty-space skipping "
-                            "executes most of them without fetching a texel; compare kernel_ms, not this fraction")
+        # ---- the same workload on float32 rings: the layout the reference itself stores (r32float textures,
+        # _wrapping_buffer.py:50-53; its pyramid builders write float32 sources, create_mouse_multiscale.py:82), where the
+        # 4 B per ray-step of SURVEY.md 8d are the bytes really stored
+        if (world == 1 and not collective and not args.no_float32_block and args.ring_storage == "native"
+                and args.source_dtype == "uint8" and vol._rings.density_storage != "float32"):
+            spec32 = (config5_spec if cfg == "C5" else config2_spec)(n, W, H, camera, pairs)
+            spec32.ring_storage = "float32"
+            t0 = time.time()
+            scene32 = testing.build(spec32, device=local_rank)
+            scene32.volume.synchronize()
+            h32 = Harness(scene32.volume)
+            h32.set_variant(args.variant)
+            m32 = h32.measure(args.in_flight, 0.1)
+            assert m32["counts"] == counts, "float32 rings must execute the same iterations and hit the same rays"
+            b32 = result_blocks(m32, "float32", True)
+            b32["what"] = ("the same volume, camera, material and frame on float32 rings — the reference's own ring layout "
+                           "(r32float, _wrapping_buffer.py:50-53): every pixel, label and step count is identical to the native-ring "
+                           "frame; 4 B/ray-step is what these rings really store")
+            b32["ring_upload_s"] = round(time.time() - t0, 2)
+            result["float32_rings"] = b32
+            del h32, m32, scene32
+            torch.cuda.empty_cache()
     else:
         # ---- C4: the fly-through.  A step = one frame = render + center_on_position(asynchronous=True).
         poses = flythrough_poses(spec, args.warmup + steps)
@@ -498,7 +568,7 @@ def main():
         # needs no streaming: one instrumented render per pose
         set_mode(True)
         path_steps = [instrumented(c)["steps"] for c in cams[args.warmup:]]
-        loop = FrameLoop(1)
+        loop = harness.loop(1)
 
         def fly(mode, asynchronous):
             """Back to the start, W untimed frames, then K timed ones; per-frame wall times (frame k = enqueue the render,

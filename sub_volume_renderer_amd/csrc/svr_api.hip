@@ -179,6 +179,7 @@ int svr_destroy(svr_ctx* c) {
         if (t.dev) (void)hipFree(t.dev);
         if (t.host) (void)hipHostFree(t.host);
         if (t.copied) (void)hipEventDestroy(t.copied);
+        if (t.drawn) (void)hipEventDestroy(t.drawn);
     }
     if (c->uploads_published) (void)hipEventDestroy(c->uploads_published);
     for (auto& m : c->render_marks) if (m.done) (void)hipEventDestroy(m.done);
@@ -787,14 +788,18 @@ static int tile_order_by_cost_for(svr_ctx* c, const MarchParams& P, int tile_w, 
     DeviceGuard guard(c->device);
     if (!slot) {
         if (c->cost_orders.size() >= 64) {                   // a caller cycling through many streams: recycle the oldest slot
+            // (wait for the last draw that read the old table, through the slot's own event: the stream it ran on may
+            // be gone by now)
             svr_ctx::CostOrder old = c->cost_orders.front();
-            SVR_HIP_TRY(hipStreamSynchronize(old.stream));
+            if (old.drawn_set) SVR_HIP_TRY(hipEventSynchronize(old.drawn));
+            else if (old.valid) SVR_HIP_TRY(hipEventSynchronize(old.copied));
             c->cost_orders.erase(c->cost_orders.begin());
-            old.stream = stream; old.valid = false;
+            old.stream = stream; old.valid = false; old.drawn_set = false;
             c->cost_orders.push_back(old);
         } else {
-            svr_ctx::CostOrder t{ stream, nullptr, nullptr, 0, nullptr, 0, false };
+            svr_ctx::CostOrder t{ stream, nullptr, nullptr, 0, nullptr, 0, false, nullptr, false };
             SVR_HIP_TRY(hipEventCreateWithFlags(&t.copied, hipEventDisableTiming));
+            SVR_HIP_TRY(hipEventCreateWithFlags(&t.drawn, hipEventDisableTiming));
             c->cost_orders.push_back(t);
         }
         slot = &c->cost_orders.back();
@@ -832,6 +837,17 @@ static bool span_addressable(const svr_ctx* c) {
             (uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
             (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
     return true;
+}
+
+// Behind a draw that may have read a cost-sorted table: mark the stream's slot (see CostOrder::drawn).
+static int cost_order_drawn(svr_ctx* c, const MarchParams& P, hipStream_t stream) {
+    for (auto& t : c->cost_orders)
+        if (t.stream == stream && t.dev == P.tile_order) {
+            SVR_HIP_TRY(hipEventRecord(t.drawn, stream));
+            t.drawn_set = true;
+            break;
+        }
+    return SVR_OK;
 }
 
 static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr_outputs* out, hipStream_t stream,
@@ -1036,6 +1052,7 @@ int svr_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, const svr
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c->have_published) SVR_HIP_TRY(hipStreamWaitEvent(s, c->uploads_published, 0));
     SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
+    { const int rco = cost_order_drawn(c, P, s); if (rco) return rco; }
     return mark_render(c, s);
 }
 
@@ -1051,6 +1068,7 @@ int svr_time_render(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, cons
     SVR_HIP_TRY(hipEventRecord(c->ev_a, s));
     for (int i = 0; i < iters; ++i) SVR_HIP_TRY(svr_launch_march(P, (c->variant & 3) == 1 ? 1 : 0, s));
     SVR_HIP_TRY(hipEventRecord(c->ev_b, s));
+    { const int rco = cost_order_drawn(c, P, s); if (rco) return rco; }
     { const int rcm = mark_render(c, s); if (rcm) return rcm; }
     SVR_HIP_TRY(hipEventSynchronize(c->ev_b));
     float ms = 0.f;

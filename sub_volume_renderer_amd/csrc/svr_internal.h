@@ -186,7 +186,10 @@ struct svr_ctx {
     std::vector<TileOrder> tile_orders;
     // cost-sorted block -> tile tables (default placement): one per stream that carries renders, rewritten (through
     // pinned memory, on that stream) whenever the camera or the frame region changes
-    struct CostOrder { hipStream_t stream; uint32_t* dev; uint32_t* host; size_t cap; hipEvent_t copied; uint64_t key; bool valid; };
+    // (`drawn`: recorded behind every draw that reads the table — what a recycled slot waits for; a recycled entry's
+    // stream handle is never used again: its owner may have destroyed the stream)
+    struct CostOrder { hipStream_t stream; uint32_t* dev; uint32_t* host; size_t cap; hipEvent_t copied; uint64_t key; bool valid;
+                       hipEvent_t drawn; bool drawn_set; };
     std::vector<CostOrder> cost_orders;
     hipEvent_t uploads_marker;       // svr_mark_uploads / svr_uploads_pending
     std::atomic<bool> marker_set;

@@ -37,6 +37,18 @@ def _grid_for(world: int, tiling: str) -> tuple[int, int]:
     return gx, gy
 
 
+class _StreamEvent:
+    """`wait()` like a torch.distributed work handle: the CURRENT stream waits for the event (no host block)."""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        import torch
+
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class TiledFrame:
     """Decomposition of a ``width x height`` frame over ``world`` ranks and the gather of its pieces."""
 
@@ -185,7 +197,14 @@ class TiledFrame:
             stream = torch.cuda.current_stream(planes[0].device).cuda_stream
             N.check(N.lib().svr_gather_tiles(comm_volume._rings.handle, n, loc, gat, nbytes, dst, C.c_void_p(stream)),
                     "svr_gather_tiles")
-            works = []                                    # ordered by the stream itself
+            # the transfers are ordered on THIS stream only: an event behind them lets finish() run on any other stream
+            # (root: before it un-tiles `gathered`; every rank: before the caller renders into `local` again)
+            events = self.__dict__.setdefault("_slot_events", {})
+            ev = events.get(slot)
+            if ev is None:
+                ev = events[slot] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(planes[0].device))
+            works = [_StreamEvent(ev, planes[0].device)]
         else:
             works = [dist.gather(t, list(b[i][0].unbind(0)) if self.rank == dst else None, dst=dst, async_op=True)
                      for i, t in enumerate(planes)]
@@ -202,8 +221,8 @@ class TiledFrame:
         if isinstance(works, str):                    # no collective: the local buffers are the frame
             return planes[0] if single else tuple(planes)
         for w in works:
-            w.wait()                                  # the current stream waits for that collective only
-        if self.rank != dst:
+            w.wait()                                  # the current stream waits for that collective only (both transports,
+        if self.rank != dst:                          # root and non-root alike: `local` may be rendered into again after this)
             return None
         frames = [self.untile(g, out, volume or self._comm_volume) for g, out in self._slot_bufs[slot]]
         return frames[0] if single else tuple(frames)

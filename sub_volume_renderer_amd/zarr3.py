@@ -13,7 +13,9 @@ specs): regular chunk grids; ``default`` and ``v2`` chunk key encodings; fill va
 chains ``[transpose] -> bytes | sharding_indexed -> [gzip | zstd | crc32c]*``; shards with the index at the end or
 the start, read chunk-wise (only the index and the inner chunks a request touches are read from the file).
 ``blosc`` is refused with a clear error: no blosc library exists here (zstd comes from the system's libzstd
-through ctypes; gzip from zlib).  The format knowledge is restated from the published zarr v3 specification; no
+through ctypes; gzip from zlib).  A ``crc32c`` checksum is verified for every payload, whatever its size
+(``csrc/host_codecs.c`` when built, a Python loop otherwise); a zstd frame that claims more bytes than its chunk
+can hold is refused before anything is allocated.  The format knowledge is restated from the published zarr v3 specification; no
 fixture written by zarr-python is available offline, so interoperability is *unpinned* — ``tests/test_zarr3.py``
 pins the reader against hand-assembled byte strings of the spec's layout and against this module's own writer.
 """
@@ -70,6 +72,8 @@ def _zstd_decompress(data: bytes, expected: int | None) -> bytes:
         if expected is None:
             raise ValueError("zstd frame without a content size")
         size = expected
+    elif expected is not None and size > expected:   # never allocate what a (corrupt) frame header asks for
+        raise ValueError(f"zstd frame claims {size} bytes, the chunk holds {expected}")
     out = ctypes.create_string_buffer(int(size) or 1)
     n = lib.ZSTD_decompress(out, int(size), data, len(data))
     if lib.ZSTD_isError(n):
@@ -88,10 +92,24 @@ def _zstd_compress(data: bytes, level: int = 3) -> bytes:
 
 
 _CRC32C_TABLE = None
+_codec_lib = False          # False: not looked for yet; None: not built
 
 
-def crc32c(data: bytes) -> int:
-    """CRC-32C (Castagnoli), as the ``crc32c`` codec appends it (little endian)."""
+def _host_codecs():
+    """``csrc/libsvr_hostcodec.so`` (host_codecs.c, built by ``__graft_entry__.build()``), or ``None``."""
+    global _codec_lib
+    if _codec_lib is False:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsvr_hostcodec.so")
+        _codec_lib = None
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            lib.svr_crc32c.restype = ctypes.c_uint32
+            lib.svr_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+            _codec_lib = lib
+    return _codec_lib
+
+
+def _crc32c_python(data: bytes) -> int:
     global _CRC32C_TABLE
     if _CRC32C_TABLE is None:
         table = []
@@ -107,6 +125,15 @@ def crc32c(data: bytes) -> int:
     return crc ^ 0xFFFFFFFF
 
 
+def crc32c(data: bytes) -> int:
+    """CRC-32C (Castagnoli), as the ``crc32c`` codec appends it (little endian).  Every payload is summed, whatever
+    its size: by ``host_codecs.c`` when it has been built, else by a (slow) Python loop."""
+    lib = _host_codecs()
+    if lib is not None:
+        return int(lib.svr_crc32c(bytes(data), len(data), 0))
+    return _crc32c_python(data)
+
+
 def _decode_bytes_codecs(codecs, data: bytes, expected: int | None) -> bytes:
     for c in reversed(codecs):
         name = c["name"]
@@ -116,7 +143,7 @@ def _decode_bytes_codecs(codecs, data: bytes, expected: int | None) -> bytes:
             data = _zstd_decompress(data, expected)
         elif name == "crc32c":
             body, tail = data[:-4], data[-4:]
-            if len(body) <= (1 << 16) and struct.unpack("<I", tail)[0] != crc32c(body):    # big chunks: not re-summed in python
+            if len(data) < 4 or struct.unpack("<I", tail)[0] != crc32c(body):
                 raise ValueError("crc32c mismatch")
             data = body
         elif name == "blosc":

@@ -160,3 +160,40 @@ def test_untile_kernels_equal_the_host_permutation(W, H, world, tiling):
         got = tf.untile(gathered.cuda(), torch.zeros((H, W, *tail), dtype=dtype, device="cuda"), holder)
         torch.cuda.synchronize()
         assert torch.equal(got.cpu(), want), (dtype, tail)
+
+
+def test_draws_on_many_short_lived_streams_and_rejected_experiment_bits():
+    """A caller that creates a HIP stream per frame and destroys it afterwards: the library keeps per-stream state (the
+    cost-sorted placement table, render marks) for 64 streams and recycles the oldest entry — through the entry's own
+    events, never through the stream handle, which is gone by then.  Every frame equals the first."""
+    import ctypes as C
+
+    import torch
+
+    scene = testing.build(testing.synthetic_spec(64, 160, 96, threshold=0.4))
+    vol, cam = scene.volume, scene.camera
+    first = vol.render(cam, 160, 96)
+    torch.cuda.synchronize()
+    want = first.rgba.clone()
+    hip = C.CDLL("libamdhip64.so")                             # the runtime torch already loaded
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    for k in range(150):
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        if k % 3 == 0:                                          # a new camera now and then: the table is rebuilt on that stream
+            scene.spec.cam_position = tuple(np.array(scene.spec.cam_position) + (0.5 if k % 6 == 0 else -0.5))
+            cam_k = scene.spec.camera()
+        r = vol.render(cam_k, 160, 96, stream=s.value)
+        r = vol.render(cam, 160, 96, stream=s.value)
+        assert hip.hipStreamSynchronize(s) == 0
+        assert torch.equal(r.rgba, want), k
+        assert hip.hipStreamDestroy(s) == 0
+    # the shipped library knows no timing-experiment bits (they render wrong pixels): rejected, state unchanged
+    for bits in (1 << 11, 1 << 12, 3 << 11):
+        with pytest.raises(ValueError, match="SVR_EXPERIMENTS"):
+            N.check(N.lib().svr_set_variant(vol.prepare(), bits), "svr_set_variant")
+    r = vol.render(cam, 160, 96)
+    torch.cuda.synchronize()
+    assert torch.equal(r.rgba, want)

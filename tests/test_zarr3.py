@@ -24,6 +24,32 @@ def test_crc32c_check_value():
     assert zarr3.crc32c(b"") == 0
 
 
+def test_crc32c_is_verified_at_every_size_and_agrees_with_the_python_loop():
+    """Round 2 verified checksums only up to 64 KiB; a corrupt large chunk must be refused like a small one."""
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 8, 9, 4096, 65536, 65537, 300001):
+        body = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        crc = zarr3.crc32c(body)
+        if n <= 65537:
+            assert crc == zarr3._crc32c_python(body)
+        framed = body + struct.pack("<I", crc)
+        codecs = [{"name": "crc32c"}]
+        assert zarr3._decode_bytes_codecs(codecs, framed, None) == body
+        bad = bytearray(framed)
+        bad[n // 2] ^= 0x10
+        with pytest.raises(ValueError, match="crc32c"):
+            zarr3._decode_bytes_codecs(codecs, bytes(bad), None)
+    with pytest.raises(ValueError, match="crc32c"):
+        zarr3._decode_bytes_codecs([{"name": "crc32c"}], b"\x01\x02", None)        # shorter than a checksum
+
+
+def test_zstd_frame_larger_than_its_chunk_is_refused():
+    big = zarr3._zstd_compress(bytes(1 << 20))
+    with pytest.raises(ValueError, match="zstd frame claims"):
+        zarr3._zstd_decompress(big, expected=4096)
+    assert zarr3._zstd_decompress(big, expected=1 << 20) == bytes(1 << 20)
+
+
 def test_hand_assembled_plain_chunks_big_endian_and_missing_chunk(tmp_path):
     root = str(tmp_path / "a.zarr")
     meta = {"zarr_format": 3, "node_type": "array", "shape": [4, 5], "data_type": "uint16",

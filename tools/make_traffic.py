@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/<round>/traffic.json from the PMC passes of tools/profile_bench.sh: HBM-side bytes per march launch
+"""One entry of profiles/<round>/traffic.json from the PMC passes of tools/profile_bench.sh: HBM-side bytes per march launch
 (FETCH_SIZE and WRITE_SIZE collected in separate passes, gfx950 correction applied as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes), stamped with the command, the workload and the hash of the
 kernel sources it was taken on — bench.py only carries the figure into `roofline.traffic` when all of them match
-what it is running.  usage: make_traffic.py <profile_dir> <out.json> <command...>"""
+what it is running — and `binding`: the resource the SQ / TA counters of the same passes show busiest.
+usage: make_traffic.py <profile_dir> <out.json> <command...>"""
 import csv
 import glob
 import json
@@ -20,7 +21,9 @@ command = " ".join(sys.argv[3:])
 
 def mean_counter(name, pat="8, false,"):        # the production build of march_span (not the instrumented <..., true, ...> one)
     vals = []
-    for f in glob.glob(os.path.join(prof, "*", "**", "*counter_collection.csv"), recursive=True):
+    # (the full-mode passes only: the LMIP-only passes live in lmip_pmc_* beside them — round 2's glob took those in too,
+    # 5 LMIP dispatches among 60)
+    for f in glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == name and pat in r["Kernel_Name"]:
@@ -52,6 +55,37 @@ doc = {
     "note": "FETCH_SIZE counts the L2's memory-side (fabric) read requests; Infinity Cache hits are included, not "
             "excluded: read it as L2-miss bytes, an upper bound on HBM bytes.",
 }
+# ---- what binds the kernel: busy share of the candidates, from the same passes
+# (SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units": x 4 = SIMD cycles;
+#  GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the kernel's duration in shader cycles; TA_BUSY_avr is per TA)
+insts_valu, _ = mean_counter("SQ_INSTS_VALU")
+act_valu, _ = mean_counter("SQ_ACTIVE_INST_VALU")
+gui, _ = mean_counter("GRBM_GUI_ACTIVE")
+ta_busy, _ = mean_counter("TA_BUSY_avr")
+tcp_stall, _ = mean_counter("TCP_PENDING_STALL_CYCLES_sum")
+wave_cycles, _ = mean_counter("SQ_WAVE_CYCLES")
+wait_any, _ = mean_counter("SQ_WAIT_ANY")
+SIMDS, CUS = 1024, 256
+if insts_valu and act_valu and gui:
+    cycles = gui / 8.0
+    cand = {"valu_issue": 4.0 * act_valu / (SIMDS * cycles)}
+    if ta_busy:
+        cand["ta_address_path"] = ta_busy / cycles
+    if tcp_stall:
+        cand["l1_miss_stall"] = tcp_stall / (CUS * cycles)
+    top = max(cand, key=cand.get)
+    doc["binding"] = {
+        "resource": top, "frac": cand[top], "insts": insts_valu,
+        "kernel_cycles": cycles,
+        "busy_share": {k: round(v, 4) for k, v in cand.items()},
+        "hbm_busy_share": round(doc["traffic_bytes_per_launch"] / (cycles / 2.4e9) / 8e12, 4) if cycles else None,
+        "def": "valu_issue = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x kernel cycles); ta_address_path = TA_BUSY_avr / "
+               "kernel cycles; l1_miss_stall = TCP_PENDING_STALL_CYCLES_sum / (256 CUs x kernel cycles); kernel cycles = "
+               "GRBM_GUI_ACTIVE / 8 (under the profiler); hbm_busy_share = traffic at 2.4 GHz nominal over 8 TB/s",
+        "wave_residency": {"waiting_share": (wait_any / wave_cycles) if wave_cycles and wait_any else None},
+        "SQ_INSTS_VALU": insts_valu, "SQ_ACTIVE_INST_VALU": act_valu, "GRBM_GUI_ACTIVE": gui,
+        "TA_BUSY_avr": ta_busy, "TCP_PENDING_STALL_CYCLES_sum": tcp_stall,
+    }
 with open(out, "w") as f:
     json.dump(doc, f, indent=1)
-print(json.dumps(doc["workload"]), doc["traffic_bytes_per_launch"])
+print(json.dumps(doc["workload"]), doc["traffic_bytes_per_launch"], json.dumps(doc.get("binding", {}).get("busy_share")))

@@ -25,10 +25,16 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
     for r in rows(f):
         if pat in r["Kernel_Name"] and r["Kernel_Name"] not in seen:      # one line per distinct kernel
             seen.add(r["Kernel_Name"])
-            print(f"dispatch: {r['Kernel_Name'][:70]} grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} vgpr={r['VGPR_Count']} "
-                  f"agpr={r.get('Accum_VGPR_Count')} sgpr={r['SGPR_Count']} lds={r['LDS_Block_Size']} scratch={r['Scratch_Size']}")
+            # rocprofv3's own units: VGPR_Count is not the code object's .vgpr_count (a 91-VGPR kernel reads 48 here) and
+            # LDS_Block_Size leaves out the dynamic LDS of the launch (8 KiB per wave for the brick region): the code
+            # object's figures are what tools/kernel_regs.py prints
+            print(f"dispatch: {r['Kernel_Name'][:70]} grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} "
+                  f"rocprofv3_VGPR_Count={r['VGPR_Count']} rocprofv3_Accum_VGPR_Count={r.get('Accum_VGPR_Count')} "
+                  f"rocprofv3_SGPR_Count={r['SGPR_Count']} LDS_Block_Size(static only)={r['LDS_Block_Size']} scratch={r['Scratch_Size']}")
 acc = defaultdict(list)
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+    if os.sep + "lmip_pmc_" in f:               # profile_bench.sh keeps its LMIP-only passes beside the full-mode ones
+        continue
     for r in rows(f):
         if pat in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
