@@ -82,6 +82,12 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: run the N > 1 pipeline (tiling, RCCL gather, un-tile) in a one-rank process group")
     ap.add_argument("--blocking-too", action="store_true", help="C4: also time the fly-through with blocking reloads")
+    ap.add_argument("--source", choices=["zarr3", "synth"], default="zarr3",
+                    help="C4: where the backing arrays come from.  zarr3 (default, what BASELINE config 4 says): a sparse, sharded, "
+                         "zstd zarr v3 store of the fly-through's corridor (16^3 chunks in 64^3 shards, the layout of the reference's "
+                         "builders), written to local disk during setup and read back through sub_volume_renderer_amd.zarr3; "
+                         "synth: lazy arrays that generate every block on demand from the closed form (no store)")
+    ap.add_argument("--store-dir", default=None, help="C4 --source zarr3: where to write the store (default: a fresh directory under $TMPDIR)")
     return ap.parse_args()
 
 
@@ -144,6 +150,78 @@ def flythrough_poses(spec, frames, step=2.0):
     d = np.array(spec.cam_target, float) - eye
     d /= np.linalg.norm(d)
     return [(tuple(eye + d * step * k), tuple(eye + d * step * k + d)) for k in range(frames)]
+
+
+def corridor_shards(spec, positions, shard=64):
+    """Per LOD, the set of shard indices (numpy order) the ring windows of `center_on_position(p)` touch for p in
+    `positions`: exactly the windows `_wobject.center_on_position` would request (default sizes), computed by the
+    product's own host logic on a volume that never touches the device."""
+    from itertools import product
+
+    import numpy as np
+
+    from sub_volume_renderer_amd import Roi, SubVolume, SubVolumeMaterial
+
+    plan = SubVolume(SubVolumeMaterial(lmip_threshold=1.0), list(spec.pairs), list(spec.ring_shapes), list(spec.chunk_shapes))
+    touched = [set() for _ in plan.wrapping_buffers]
+    for pos in positions:
+        p = (plan.world.inverse_matrix @ np.array([*pos, 1.0]))[:3][::-1]
+        for lod, b in enumerate(plan.wrapping_buffers):
+            size = tuple((n - 1) * c for n, c in zip(b.shape_in_chunks, b.chunk_shape_in_pixels))
+            offset = tuple(int(c * f - s // 2) for c, s, f in zip(p, size, b.scale_factor))
+            roi = b.get_snapped_roi_in_pixels(Roi(offset, size))
+            if roi.empty:
+                continue
+            lo = [max(0, int(v)) for v in roi.begin]
+            hi = [min(int(d), int(v)) for d, v in zip(b.backing_data.shape, roi.end)]
+            if any(h <= l for l, h in zip(lo, hi)):
+                continue
+            touched[lod].update(product(*[range(l // shard, (h - 1) // shard + 1) for l, h in zip(lo, hi)]))
+    return touched
+
+
+def write_corridor_store(root, n, n_labels, touched, shard=64, chunk=16):
+    """The zarr v3 store of config 4: group `raw.zarr` / `labels.zarr` with arrays `scale0..2` (uint8 / uint32), 16^3
+    chunks in 64^3 shards, `bytes` + `zstd` — the layout of scripts/create_mouse_multiscale.py:102-131 — holding ONLY
+    the shards in `touched` (every other shard is missing = fill value 0; the fly-through never reads them).  The
+    voxels come from the closed form (`synth.block_host`), a row of shards per call."""
+    import time
+
+    import numpy as np
+
+    from sub_volume_renderer_amd import synth, zarr3
+
+    t0 = time.time()
+    stats = {"shards": 0, "bytes_on_disk": 0, "raw_bytes": 0}
+    groups = {"raw": zarr3.create_group(os.path.join(root, "raw.zarr")), "labels": zarr3.create_group(os.path.join(root, "labels.zarr"))}
+    arrays = []
+    for lod, shards in enumerate(touched):
+        m = n >> lod
+        dens = zarr3.create_array(os.path.join(groups["raw"].path, f"scale{lod}"), (m, m, m), np.uint8, (chunk,) * 3, (shard,) * 3)
+        labs = zarr3.create_array(os.path.join(groups["labels"].path, f"scale{lod}"), (m, m, m), np.uint32, (chunk,) * 3, (shard,) * 3)
+        rows = {}
+        for i0, i1, i2 in sorted(shards):
+            rows.setdefault((i0, i1), []).append(i2)
+        for (i0, i1), cols in rows.items():
+            cols.sort()
+            k = 0
+            while k < len(cols):                         # runs of consecutive shards along the contiguous axis: one generator call
+                j = k
+                while j + 1 < len(cols) and cols[j + 1] == cols[j] + 1:
+                    j += 1
+                off = (i0 * shard, i1 * shard, cols[k] * shard)
+                shape = tuple(min(s, m - o) for s, o in zip((shard, shard, (cols[j] - cols[k] + 1) * shard), off))
+                d, l = synth.block_host(n, lod, off, shape, n_labels, nthreads=0)
+                for q in range(k, j + 1):
+                    a2 = (cols[q] - cols[k]) * shard
+                    stats["bytes_on_disk"] += zarr3.write_block(dens, (i0, i1, cols[q]), d[:, :, a2:a2 + shard])
+                    stats["bytes_on_disk"] += zarr3.write_block(labs, (i0, i1, cols[q]), l[:, :, a2:a2 + shard])
+                    stats["shards"] += 2
+                stats["raw_bytes"] += d.nbytes + l.nbytes
+                k = j + 1
+        arrays.append((zarr3.open_zarr(dens.path), zarr3.open_zarr(labs.path)))
+    stats["write_seconds"] = round(time.time() - t0, 2)
+    return arrays, stats
 
 
 def kernel_source_hash():
@@ -213,8 +291,20 @@ def main():
 
     # ---- the volume and its rings -------------------------------------------------------------------
     t0 = time.time()
+    store = None
     if cfg == "C4":
         spec = config4_spec(n, W, H)
+        if args.source == "zarr3":
+            # the store of the fly-through's corridor, written now (setup), read during the timed region
+            import tempfile
+
+            g.build_host_codecs()
+            positions = [spec.cam_position] + [eye for eye, _ in flythrough_poses(spec, args.warmup + steps)]
+            touched = corridor_shards(spec, positions)
+            root = args.store_dir or tempfile.mkdtemp(prefix="svr_c4_store_")
+            arrays, store = write_corridor_store(root, n, n_labels, touched)
+            store["path"] = root
+            spec.pairs = arrays                              # zarr arrays as backing data, as the reference is fed (README.md:18)
     else:
         # LOD 0 from the closed form; the coarser levels with the GPU pyramid builder (svr_pool2x, the reference's
         # 2x mean / max pooling rules) — bit-identical to synthesising every level (tests/test_pyramid.py)
@@ -232,7 +322,21 @@ def main():
             spec.material.update(lmip_threshold=spec.material["lmip_threshold"] * scale16, clim=(0.0, 255.0 * scale16))
     t_gen = time.time() - t0
     spec.ring_storage = args.ring_storage
-    synth.LazyLod.read_seconds, synth.LazyLod.read_bytes = 0.0, 0
+    def source_stats(reset=False):
+        """(seconds inside the backing arrays' reads, decoded bytes handed out, stored bytes read) since the last reset:
+        the lazy generator keeps them on its class, a zarr array on each instance."""
+        sec, dec, sto = synth.LazyLod.read_seconds, synth.LazyLod.read_bytes, 0
+        for pair in spec.pairs:
+            for a in pair:
+                if hasattr(a, "stored_bytes"):
+                    sec, dec, sto = sec + a.read_seconds, dec + a.read_bytes, sto + a.stored_bytes
+                    if reset:
+                        a.read_seconds, a.read_bytes, a.stored_bytes = 0.0, 0, 0
+        if reset:
+            source_stats(reset=True)
+        return sec, dec, sto
+
+    source_stats(reset=True)
     t0 = time.time()
     scene = testing.build(spec, device=local_rank)
     scene.volume.synchronize()
@@ -247,7 +351,7 @@ def main():
         return int(b.value), float(s.value)
 
     fill_bytes, fill_seconds = upload_stats(reset=True)
-    fill_read_s = synth.LazyLod.read_seconds
+    fill_read_s = source_stats()[0]
 
     tiled = TiledFrame(W, H, rank, world, args.band_h, force_collective=args.force_collective, tiling=args.tiling)
     transport = "none"
@@ -578,7 +682,7 @@ def main():
             vol.center_on_position(poses[0][0])                            # blocking: rings as at the start
             vol.synchronize()
             upload_stats(reset=True)
-            synth.LazyLod.read_seconds, synth.LazyLod.read_bytes = 0.0, 0
+            source_stats(reset=True)
             times = []
             if collective:
                 dist.barrier()
@@ -604,6 +708,7 @@ def main():
             landed = vol.poll_uploads(wait=False)
             vol.poll_uploads(wait=True)
             ub, us = upload_stats()
+            src = source_stats()
             if collective:
                 tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -614,8 +719,10 @@ def main():
                         upload={"staged_bytes": ub, "seconds_in_upload_calls": round(us, 4),
                                 "GBps": (ub / us / 1e9) if us > 0 else None,
                                 "frac_of_pcie_gen5_x16": (ub / us / 1e9 / PCIE_PEAK_GBS) if us > 0 else None,
-                                "source_read_seconds": round(synth.LazyLod.read_seconds, 3),
-                                "source_read_GBps": (synth.LazyLod.read_bytes / synth.LazyLod.read_seconds / 1e9) if synth.LazyLod.read_seconds else None,
+                                "source": "zarr v3 store (sharded, zstd) read through sub_volume_renderer_amd.zarr3" if store else "lazy closed-form generator",
+                                "source_read_seconds": round(src[0], 3),
+                                "source_read_GBps": (src[1] / src[0] / 1e9) if src[0] else None,          # decoded bytes handed to the rings
+                                "source_stored_GBps": (src[2] / src[0] / 1e9) if (src[0] and src[2]) else None,   # compressed bytes read from disk
                                 "all_loads_landed_at_last_frame": bool(landed)})
 
         runs = {"full": fly("full", True)}
@@ -631,7 +738,8 @@ def main():
                 "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": r["dt"] / steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {
-                    "workload": f"C4: {n}^3 volume generated chunk-wise behind a lazy array (never resident), 3 LODs, chunks "
+                    "workload": f"C4: {n}^3 volume " + ("behind a zarr v3 store (16^3 chunks in 64^3 shards, zstd; only the fly-through's corridor is stored), "
+                                                         if store else "generated chunk-wise behind a lazy array, ") + "never resident, 3 LODs, chunks "
                                 f"(16,16,48)/(8,8,48)/(4,4,48), rings {spec.ring_shapes} chunks, {W}x{H}, K2 fly-through "
                                 f"2 voxels/frame, center_on_position(asynchronous=True) every frame, march_mode=full",
                     "ray_steps_total": int(sum(path_steps)),
@@ -645,6 +753,8 @@ def main():
                                  "source_read_seconds": round(fill_read_s, 2), "wall_seconds": round(t_load, 2)},
                 "setup_s": {"describe": round(t_gen, 2), "initial_fill": round(t_load, 2)},
             }
+            if store:
+                result["store"] = store
             for name in ("lmip", "full_blocking"):
                 if name in runs:
                     q = runs[name]

@@ -44,20 +44,116 @@ uint32_t svr_crc32c(const void* data, size_t n, uint32_t crc) {
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Batch decode / encode of zarr v3 inner chunks (3-D, `bytes` little endian -> [zstd] -> [crc32c]), many chunks per call,
- * OpenMP over chunks: the native half of zarr3.py's reader — what zarr-python / tensorstore do in C++ for the
+ * a thread pool over chunks: the native half of zarr3.py's reader — what zarr-python / tensorstore do in C++ for the
  * reference (README.md:18, _wrapping_buffer.py:307-322).  libzstd is bound at run time (no headers on the target).
  * --------------------------------------------------------------------------------------------------------------- */
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdlib.h>
-#ifdef _OPENMP
-#include <omp.h>
-#endif
+
+/* A small persistent thread pool: workers SLEEP on a condition variable between jobs (an OpenMP team spins after
+ * every parallel region, and a spinning team beside the render thread burns the cgroup CPU quota of a one-GPU job:
+ * 30-60 ms stalls per read were measured that way).  One job at a time (callers are serialised by a mutex); items
+ * are claimed one by one from an atomic counter, the calling thread works too. */
+#define POOL_MAX 64
+typedef void (*pool_fn)(int item, int worker, void* arg);
+static struct {
+    pthread_mutex_t mu, job_mu;
+    pthread_cond_t wake, done;
+    pthread_t th[POOL_MAX];
+    int nthreads, generation, active, want;      /* want: workers allowed on the current job */
+    pool_fn fn; void* arg; int nitems;
+    atomic_int next;
+    int init;
+} pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+
+static void pool_drain(int worker) {
+    for (;;) {
+        const int k = atomic_fetch_add(&pool.next, 1);
+        if (k >= pool.nitems) return;
+        pool.fn(k, worker, pool.arg);
+    }
+}
+
+static int pool_start_gen[POOL_MAX + 1];     /* the generation a worker was created in (set under pool.mu by its creator) */
+
+/* Pin worker `id` to the id-th CPU this process may run on.  A thread woken for a job of a few milliseconds otherwise
+ * starts on its waker's CPU and the scheduler does not spread the team before the job is over (measured: 8 threads, one
+ * CPU's worth of progress on 60 us items). */
+static void pool_pin(int id) {
+    cpu_set_t allowed, one;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int count = CPU_COUNT(&allowed);
+    if (count < 2) return;
+    int want = id % count, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &allowed) && seen++ == want) {
+            CPU_ZERO(&one); CPU_SET(c, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            return;
+        }
+}
+
+static void* pool_worker(void* p) {
+    const int id = (int)(intptr_t)p;
+    pool_pin(id);
+    pthread_mutex_lock(&pool.mu);
+    int seen = pool_start_gen[id];
+    for (;;) {
+        while (pool.generation == seen) pthread_cond_wait(&pool.wake, &pool.mu);
+        seen = pool.generation;
+        if (id > pool.want) continue;                     /* this job runs on fewer threads */
+        pthread_mutex_unlock(&pool.mu);
+        pool_drain(id);
+        pthread_mutex_lock(&pool.mu);
+        if (--pool.active == 0) pthread_cond_signal(&pool.done);
+    }
+    return NULL;
+}
+
+/* run fn(item, worker, arg) for item in [0, n) on up to nthreads threads (worker ids 0 .. nthreads - 1; 0 = the caller) */
+static void pool_run(int n, int nthreads, pool_fn fn, void* arg) {
+    if (nthreads > POOL_MAX) nthreads = POOL_MAX;
+    if (nthreads > n) nthreads = n;
+    if (nthreads <= 1) { for (int k = 0; k < n; ++k) fn(k, 0, arg); return; }
+    pthread_mutex_lock(&pool.job_mu);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.nthreads < nthreads - 1) {
+        const int id = pool.nthreads + 1;
+        pool_start_gen[id] = pool.generation;          /* the job about to be posted is new to it */
+        if (pthread_create(&pool.th[pool.nthreads], NULL, pool_worker, (void*)(intptr_t)id) != 0) break;
+        pthread_detach(pool.th[pool.nthreads]);
+        ++pool.nthreads;
+    }
+    pool.fn = fn; pool.arg = arg; pool.nitems = n;
+    atomic_store(&pool.next, 0);
+    pool.want = nthreads - 1 < pool.nthreads ? nthreads - 1 : pool.nthreads;
+    pool.active = pool.want;
+    ++pool.generation;
+    pthread_cond_broadcast(&pool.wake);
+    pthread_mutex_unlock(&pool.mu);
+    pool_drain(0);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.active > 0) pthread_cond_wait(&pool.done, &pool.mu);
+    pthread_mutex_unlock(&pool.mu);
+    pthread_mutex_unlock(&pool.job_mu);
+}
 
 typedef size_t (*zstd_decompress_t)(void*, size_t, const void*, size_t);
 typedef size_t (*zstd_compress_t)(void*, size_t, const void*, size_t, int);
 typedef size_t (*zstd_bound_t)(size_t);
 typedef unsigned (*zstd_iserror_t)(size_t);
 typedef unsigned long long (*zstd_framesize_t)(const void*, size_t);
+typedef void* (*zstd_create_t)(void);
+typedef size_t (*zstd_free_t)(void*);
+typedef size_t (*zstd_decompress_ctx_t)(void*, void*, size_t, const void*, size_t);
+typedef size_t (*zstd_compress_ctx_t)(void*, void*, size_t, const void*, size_t, int);
+static zstd_create_t z_create_dctx, z_create_cctx;            /* one context per worker and call: ZSTD_decompress() builds */
+static zstd_free_t z_free_dctx, z_free_cctx;                  /* and frees a context per chunk (20 us for a 4 KiB chunk)     */
+static zstd_decompress_ctx_t z_decompress_ctx;
+static zstd_compress_ctx_t z_compress_ctx;
 static zstd_decompress_t z_decompress;
 static zstd_compress_t z_compress;
 static zstd_bound_t z_bound;
@@ -75,8 +171,13 @@ static int zstd_bind(void) {
         z_bound = (zstd_bound_t)dlsym(h, "ZSTD_compressBound");
         z_iserror = (zstd_iserror_t)dlsym(h, "ZSTD_isError");
         z_framesize = (zstd_framesize_t)dlsym(h, "ZSTD_getFrameContentSize");
+        z_create_dctx = (zstd_create_t)dlsym(h, "ZSTD_createDCtx"); z_free_dctx = (zstd_free_t)dlsym(h, "ZSTD_freeDCtx");
+        z_create_cctx = (zstd_create_t)dlsym(h, "ZSTD_createCCtx"); z_free_cctx = (zstd_free_t)dlsym(h, "ZSTD_freeCCtx");
+        z_decompress_ctx = (zstd_decompress_ctx_t)dlsym(h, "ZSTD_decompressDCtx");
+        z_compress_ctx = (zstd_compress_ctx_t)dlsym(h, "ZSTD_compressCCtx");
     }
-    z_state = (h && z_decompress && z_compress && z_bound && z_iserror && z_framesize) ? 1 : -1;
+    z_state = (h && z_decompress && z_compress && z_bound && z_iserror && z_framesize && z_create_dctx && z_free_dctx &&
+               z_create_cctx && z_free_cctx && z_decompress_ctx && z_compress_ctx) ? 1 : -1;
     return z_state;
 }
 
@@ -106,50 +207,54 @@ static void place_chunk(const uint8_t* block, const void* fill, int elem, const 
 }
 
 /* Decode n chunks into a strided destination box.
- *   base + off[k], nbytes[k]: the stored bytes of chunk k (off[k] == UINT64_MAX: not stored -> fill value)
+ *   base + off[k], nbytes[k]: the stored bytes of chunk k (off[k] == UINT64_MAX: not stored -> fill value;
+ *                             base == NULL: off[k] is the address itself)
  *   zstd / crc: the chunk's bytes->bytes codecs in ENCODE order zstd, then crc32c (either may be absent)
  *   origin[3 k ..]: destination coordinates of chunk k's first element (may lie outside the box: clipped)
  * Returns 0, -1 when libzstd is needed and missing, or 1 + k for the first chunk that fails (checksum mismatch,
  * corrupt frame, wrong decoded size). */
+typedef struct {
+    const uint8_t* base; const uint64_t* off; const uint64_t* nbytes; int zstd, crc, elem; const int32_t* chunk;
+    uint8_t* dst; const int64_t* strides; const int32_t* shape; const int32_t* origin; const void* fill;
+    size_t raw; uint8_t* tmp[POOL_MAX]; void* ctx[POOL_MAX]; atomic_int bad;
+} decode_job;
+
+static void decode_one(int k, int worker, void* arg) {
+    decode_job* j = (decode_job*)arg;
+    if (j->off[k] == UINT64_MAX) { place_chunk(NULL, j->fill, j->elem, j->chunk, j->dst, j->strides, j->shape, j->origin + 3 * k); return; }
+    const uint8_t* p = j->base ? j->base + j->off[k] : (const uint8_t*)(uintptr_t)j->off[k];     /* base NULL: off[] holds addresses */
+    size_t len = (size_t)j->nbytes[k];
+    int ok = 1;
+    if (j->crc) {
+        uint32_t want;
+        ok = len >= 4;
+        if (ok) { memcpy(&want, p + len - 4, 4); len -= 4; ok = svr_crc32c(p, len, 0) == want; }
+    }
+    const uint8_t* block = p;
+    if (ok && j->zstd) {
+        if (!j->tmp[worker]) { j->tmp[worker] = (uint8_t*)malloc(j->raw ? j->raw : 1); j->ctx[worker] = z_create_dctx(); }
+        uint8_t* tmp = j->tmp[worker];
+        const unsigned long long claimed = z_framesize(p, len);
+        ok = tmp && j->ctx[worker] && (claimed == j->raw || claimed >= 0xFFFFFFFFFFFFFFFEull);     /* unknown size: decode and see */
+        if (ok) { const size_t got = z_decompress_ctx(j->ctx[worker], tmp, j->raw, p, len); ok = !z_iserror(got) && got == j->raw; }
+        block = tmp;
+    } else if (ok) {
+        ok = len == j->raw;
+    }
+    if (ok) { place_chunk(block, j->fill, j->elem, j->chunk, j->dst, j->strides, j->shape, j->origin + 3 * k); return; }
+    int cur = atomic_load(&j->bad);                      /* keep the FIRST failing chunk */
+    while ((cur == 0 || k + 1 < cur) && !atomic_compare_exchange_weak(&j->bad, &cur, k + 1)) {}
+}
+
 int svr_zarr_decode_chunks(int n, const uint8_t* base, const uint64_t* off, const uint64_t* nbytes, int zstd, int crc,
                            int elem, const int32_t chunk[3], uint8_t* dst, const int64_t dst_strides[3],
                            const int32_t dst_shape[3], const int32_t* origin, const void* fill, int nthreads) {
     if (zstd && zstd_bind() != 1) return -1;
-    const size_t raw = (size_t)chunk[0] * chunk[1] * chunk[2] * (size_t)elem;
-    int bad = 0;
-    if (nthreads < 1) nthreads = 1;
-#pragma omp parallel num_threads(nthreads)
-    {
-        uint8_t* tmp = zstd ? (uint8_t*)malloc(raw ? raw : 1) : NULL;
-#pragma omp for schedule(dynamic, 8)
-        for (int k = 0; k < n; ++k) {
-            if (off[k] == UINT64_MAX) { place_chunk(NULL, fill, elem, chunk, dst, dst_strides, dst_shape, origin + 3 * k); continue; }
-            const uint8_t* p = base + off[k];
-            size_t len = (size_t)nbytes[k];
-            int ok = 1;
-            if (crc) {
-                uint32_t want;
-                ok = len >= 4;
-                if (ok) { memcpy(&want, p + len - 4, 4); len -= 4; ok = svr_crc32c(p, len, 0) == want; }
-            }
-            const uint8_t* block = p;
-            if (ok && zstd) {
-                const unsigned long long claimed = z_framesize(p, len);
-                ok = tmp && (claimed == raw || claimed >= 0xFFFFFFFFFFFFFFFEull);     /* unknown size: decode and see */
-                if (ok) { const size_t got = z_decompress(tmp, raw, p, len); ok = !z_iserror(got) && got == raw; }
-                block = tmp;
-            } else if (ok) {
-                ok = len == raw;
-            }
-            if (ok) place_chunk(block, fill, elem, chunk, dst, dst_strides, dst_shape, origin + 3 * k);
-            else {
-#pragma omp critical
-                if (!bad || k + 1 < bad) bad = k + 1;
-            }
-        }
-        free(tmp);
-    }
-    return bad;
+    decode_job j = { base, off, nbytes, zstd, crc, elem, chunk, dst, dst_strides, dst_shape, origin, fill,
+                     (size_t)chunk[0] * chunk[1] * chunk[2] * (size_t)elem, { 0 }, { 0 }, 0 };
+    pool_run(n, nthreads < 1 ? 1 : nthreads, decode_one, &j);
+    for (int w = 0; w < POOL_MAX; ++w) { free(j.tmp[w]); if (j.ctx[w]) z_free_dctx(j.ctx[w]); }
+    return atomic_load(&j.bad);
 }
 
 /* Encode n chunks cut from a C-contiguous source block of shape src_shape (elements of `elem` bytes): chunk k starts at
@@ -161,47 +266,54 @@ size_t svr_zarr_encode_bound(size_t raw, int zstd) {
     return (zstd ? z_bound(raw) : raw) + 4;
 }
 
+typedef struct {
+    const uint8_t* src; const int32_t* src_shape; const int32_t* corner; int elem; const int32_t* chunk; const void* fill;
+    int zstd, level, crc, skip_fill; uint8_t* out; size_t slot; uint64_t* out_bytes; size_t raw; uint8_t* blk[POOL_MAX]; void* ctx[POOL_MAX]; atomic_int rc;
+} encode_job;
+
+static void encode_one(int k, int worker, void* arg) {
+    encode_job* j = (encode_job*)arg;
+    if (!j->blk[worker]) { j->blk[worker] = (uint8_t*)malloc(j->raw ? j->raw : 1); if (j->zstd) j->ctx[worker] = z_create_cctx(); }
+    uint8_t* blk = j->blk[worker];
+    const int32_t* c = j->corner + 3 * k;
+    const int32_t* chunk = j->chunk; const int32_t* src_shape = j->src_shape;
+    const int elem = j->elem;
+    if (!blk || (j->zstd && !j->ctx[worker])) { atomic_store(&j->rc, -2); j->out_bytes[k] = 0; return; }
+    for (int32_t i = 0; i < chunk[0]; ++i)
+        for (int32_t jj = 0; jj < chunk[1]; ++jj) {
+            uint8_t* d = blk + ((size_t)i * chunk[1] + jj) * chunk[2] * (size_t)elem;
+            const int inside = c[0] + i < src_shape[0] && c[1] + jj < src_shape[1];
+            const int32_t have = inside ? (c[2] + chunk[2] <= src_shape[2] ? chunk[2] : (src_shape[2] > c[2] ? src_shape[2] - c[2] : 0)) : 0;
+            if (have > 0)
+                memcpy(d, j->src + (((size_t)(c[0] + i) * src_shape[1] + (c[1] + jj)) * src_shape[2] + c[2]) * (size_t)elem,
+                       (size_t)have * elem);
+            for (int32_t q = have; q < chunk[2]; ++q) memcpy(d + (size_t)q * elem, j->fill, elem);
+        }
+    if (j->skip_fill) {
+        int only_fill = 1;
+        for (size_t q = 0; q < j->raw && only_fill; q += elem) only_fill = memcmp(blk + q, j->fill, elem) == 0;
+        if (only_fill) { j->out_bytes[k] = 0; return; }
+    }
+    uint8_t* o = j->out + (size_t)k * j->slot;
+    size_t len = j->raw;
+    if (j->zstd) {
+        len = z_compress_ctx(j->ctx[worker], o, j->slot - 4, blk, j->raw, j->level);
+        if (z_iserror(len)) { atomic_store(&j->rc, -2); j->out_bytes[k] = 0; return; }
+    } else {
+        memcpy(o, blk, j->raw);
+    }
+    if (j->crc) { const uint32_t sum = svr_crc32c(o, len, 0); memcpy(o + len, &sum, 4); len += 4; }
+    j->out_bytes[k] = len;
+}
+
 int svr_zarr_encode_chunks(int n, const uint8_t* src, const int32_t src_shape[3], const int32_t* corner, int elem,
                            const int32_t chunk[3], const void* fill, int zstd, int level, int crc, int skip_fill,
                            uint8_t* out, size_t slot, uint64_t* out_bytes, int nthreads) {
     if (zstd && zstd_bind() != 1) return -1;
     const size_t raw = (size_t)chunk[0] * chunk[1] * chunk[2] * (size_t)elem;
     if (slot < (zstd ? z_bound(raw) : raw) + 4) return -2;
-    if (nthreads < 1) nthreads = 1;
-    int rc = 0;
-#pragma omp parallel num_threads(nthreads)
-    {
-        uint8_t* blk = (uint8_t*)malloc(raw ? raw : 1);
-#pragma omp for schedule(dynamic, 4)
-        for (int k = 0; k < n; ++k) {
-            const int32_t* c = corner + 3 * k;
-            int only_fill = 1;
-            for (int32_t i = 0; i < chunk[0]; ++i)
-                for (int32_t j = 0; j < chunk[1]; ++j) {
-                    uint8_t* d = blk + ((size_t)i * chunk[1] + j) * chunk[2] * (size_t)elem;
-                    const int inside = c[0] + i < src_shape[0] && c[1] + j < src_shape[1];
-                    const int32_t have = inside ? (c[2] + chunk[2] <= src_shape[2] ? chunk[2] : (src_shape[2] > c[2] ? src_shape[2] - c[2] : 0)) : 0;
-                    if (have > 0)
-                        memcpy(d, src + (((size_t)(c[0] + i) * src_shape[1] + (c[1] + j)) * src_shape[2] + c[2]) * (size_t)elem,
-                               (size_t)have * elem);
-                    for (int32_t q = have; q < chunk[2]; ++q) memcpy(d + (size_t)q * elem, fill, elem);
-                }
-            if (skip_fill) {
-                for (size_t q = 0; q < raw && only_fill; q += elem) only_fill = memcmp(blk + q, fill, elem) == 0;
-                if (only_fill) { out_bytes[k] = 0; continue; }
-            }
-            uint8_t* o = out + (size_t)k * slot;
-            size_t len = raw;
-            if (zstd) {
-                len = z_compress(o, slot - 4, blk, raw, level);
-                if (z_iserror(len)) { rc = -2; out_bytes[k] = 0; continue; }
-            } else {
-                memcpy(o, blk, raw);
-            }
-            if (crc) { const uint32_t s = svr_crc32c(o, len, 0); memcpy(o + len, &s, 4); len += 4; }
-            out_bytes[k] = len;
-        }
-        free(blk);
-    }
-    return rc;
+    encode_job j = { src, src_shape, corner, elem, chunk, fill, zstd, level, crc, skip_fill, out, slot, out_bytes, raw, { 0 }, { 0 }, 0 };
+    pool_run(n, nthreads < 1 ? 1 : nthreads, encode_one, &j);
+    for (int w = 0; w < POOL_MAX; ++w) { free(j.blk[w]); if (j.ctx[w]) z_free_cctx(j.ctx[w]); }
+    return atomic_load(&j.rc);
 }

@@ -27,6 +27,7 @@ import ctypes.util
 import json
 import os
 import struct
+import time
 import zlib
 from collections import OrderedDict
 from itertools import product
@@ -105,6 +106,15 @@ def _host_codecs():
             lib = ctypes.CDLL(path)
             lib.svr_crc32c.restype = ctypes.c_uint32
             lib.svr_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+            vp, i32p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)
+            lib.svr_zarr_decode_chunks.restype = ctypes.c_int
+            lib.svr_zarr_decode_chunks.argtypes = [ctypes.c_int, vp, u64p, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, vp,
+                                                   ctypes.POINTER(ctypes.c_int64), i32p, i32p, vp, ctypes.c_int]
+            lib.svr_zarr_encode_bound.restype = ctypes.c_size_t
+            lib.svr_zarr_encode_bound.argtypes = [ctypes.c_size_t, ctypes.c_int]
+            lib.svr_zarr_encode_chunks.restype = ctypes.c_int
+            lib.svr_zarr_encode_chunks.argtypes = [ctypes.c_int, vp, i32p, i32p, ctypes.c_int, i32p, vp, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, u64p, ctypes.c_int]
             _codec_lib = lib
     return _codec_lib
 
@@ -220,6 +230,34 @@ class _Chain:
         return _encode_bytes_codecs(self.tail, raw)
 
 
+def _native_tail(chain: "_Chain"):
+    """(zstd, crc) when the chunk codec chain is one ``host_codecs.c`` decodes — ``bytes`` (little endian, or one-byte
+    elements), then optionally ``zstd``, then optionally ``crc32c`` — else ``None`` (the Python path handles the rest)."""
+    if chain.kind != "bytes" or chain.transposes or (chain.endian == ">" and chain.dtype.itemsize > 1):
+        return None
+    names = [c["name"] for c in chain.tail]
+    if names not in ([], ["zstd"], ["crc32c"], ["zstd", "crc32c"]):
+        return None
+    return ("zstd" in names, "crc32c" in names)
+
+
+def _threads(reading: bool = True) -> int:
+    """Worker threads of the native codec: the CPUs this process may use (affinity mask capped by the cgroup quota) —
+    HALF of them for reads, which run on a streaming worker beside a render thread (a decoder team that takes the whole
+    CPU quota gets the process throttled, and a throttled render thread stalls frames); ``SVR_ZARR_THREADS`` overrides."""
+    if os.environ.get("SVR_ZARR_THREADS"):
+        return max(1, int(os.environ["SVR_ZARR_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(32, n // 2 if reading else n))
+
+
 class ZarrV3Array:
     """Read-only zarr v3 array: ``shape``, ``dtype``, ``ndim``, ``chunks`` (inner chunks when sharded, as
     zarr-python reports them), ``shards`` and ``__getitem__`` over slices / integers."""
@@ -252,6 +290,14 @@ class ZarrV3Array:
         self._cache: OrderedDict = OrderedDict()
         self._cache_chunks = cache_chunks
         self._index_cache: OrderedDict = OrderedDict()
+        # the native reader (csrc/host_codecs.c): 3-D arrays whose chunk codecs it knows; `native = False` forces the
+        # Python path (tests compare the two)
+        inner = sh["chain"] if sh else self._chain
+        self._native_codecs = _native_tail(inner) if self.ndim == 3 else None
+        self.native = True
+        # read statistics (bench.py, config C4): decoded bytes handed out, stored bytes read, seconds inside reads
+        self.read_bytes = self.stored_bytes = 0
+        self.read_seconds = 0.0
 
     def _fill(self, v):
         if isinstance(v, str):
@@ -349,6 +395,12 @@ class ZarrV3Array:
                 if not 0 <= k < n:
                     raise IndexError("index out of range")
                 lo.append(k); hi.append(k + 1); squeeze.append(True)
+        t_read = time.perf_counter()
+        if self.native and self._native_codecs is not None and _host_codecs() is not None and all(h > l for l, h in zip(lo, hi)):
+            out = self._read_native(lo, hi)
+            self.read_seconds += time.perf_counter() - t_read
+            self.read_bytes += out.nbytes
+            return out[tuple(0 if s else slice(None) for s in squeeze)]
         out = np.full([h - l for l, h in zip(lo, hi)], self.fill_value, self.dtype)
         if out.size:
             c = self.chunks
@@ -363,7 +415,82 @@ class ZarrV3Array:
                     src.append(slice(b0 - i * s, b1 - i * s))
                     dst.append(slice(b0 - l, b1 - l))
                 out[tuple(dst)] = block[tuple(src)]
+        self.read_seconds += time.perf_counter() - t_read
+        self.read_bytes += out.nbytes
         return out[tuple(0 if s else slice(None) for s in squeeze)]
+
+    def _read_native(self, lo, hi) -> np.ndarray:
+        """The box [lo, hi) through ``svr_zarr_decode_chunks``: per shard file ONE open, the index (cached) and the byte
+        ranges of the inner chunks the box touches; then every chunk of the request is checked (crc32c), decompressed
+        (zstd) and placed by a team of threads in one call."""
+        lib = _host_codecs()
+        zstd, crc = self._native_codecs
+        c = self.chunks
+        sh = self._chain.shard
+        ranges = [range(l // s, (h - 1) // s + 1) for l, h, s in zip(lo, hi, c)]
+        n = len(ranges[0]) * len(ranges[1]) * len(ranges[2])
+        idx = np.stack(np.meshgrid(*[np.asarray(r, np.int64) for r in ranges], indexing="ij"), -1).reshape(n, 3)
+        origin = np.ascontiguousarray(idx * np.asarray(c, np.int64) - np.asarray(lo, np.int64), np.int32)
+        off = np.full(n, _EMPTY, np.uint64)
+        nbytes = np.zeros(n, np.uint64)
+        per = tuple(o // i for o, i in zip(self._outer, c)) if sh else (1, 1, 1)
+        outer = idx // np.asarray(per, np.int64)
+        within = idx % np.asarray(per, np.int64)
+        # group the chunks by the file that stores them (a shard, or the chunk's own file)
+        span = outer.max(axis=0) + 1
+        key = (outer[:, 0] * span[1] + outer[:, 1]) * span[2] + outer[:, 2]
+        order = np.argsort(key, kind="stable")
+        _, starts = np.unique(key[order], return_index=True)
+        bounds = list(starts) + [n]
+        pieces, total = [], 0
+        for g in range(len(starts)):
+            members = order[bounds[g]:bounds[g + 1]]
+            o = tuple(int(v) for v in outer[members[0]])
+            path = self._file(o)
+            try:
+                f = open(path, "rb")
+            except FileNotFoundError:
+                continue                                        # not stored: fill value
+            with f:
+                if sh is None:
+                    data = np.frombuffer(f.read(), np.uint8)
+                    if data.size:
+                        off[members[0]], nbytes[members[0]] = data.ctypes.data, data.size
+                    pieces.append(data)
+                    total += data.size
+                    continue
+                index = self._shard_index(path, f, os.fstat(f.fileno()).st_size)
+                ent = index[tuple(within[members].T)]           # [m, 2] (offset, nbytes)
+                stored = ent[:, 0] != _EMPTY
+                if not stored.any():
+                    continue
+                e_off, e_len = ent[stored, 0].astype(np.int64), ent[stored, 1].astype(np.int64)
+                # one read of the span that covers the wanted chunks (they lie close together in a shard)
+                a, b = int(e_off.min()), int((e_off + e_len).max())
+                f.seek(a)
+                data = np.frombuffer(f.read(b - a), np.uint8)
+                if data.size != b - a:
+                    raise ValueError(f"shard {path} is shorter than its index says")
+                off[members[stored]] = (e_off - a + data.ctypes.data).astype(np.uint64)      # addresses (base = NULL below)
+                nbytes[members[stored]] = e_len.astype(np.uint64)
+                pieces.append(data)                             # keeps the bytes alive until the decode call returns
+                total += data.size
+        self.stored_bytes += total
+        out = np.empty([h - l for l, h in zip(lo, hi)], self.dtype)
+        fill = np.asarray(self.fill_value, self.dtype).reshape(1)
+        cs = (ctypes.c_int32 * 3)(*c)
+        strides = (ctypes.c_int64 * 3)(*out.strides)
+        shape = (ctypes.c_int32 * 3)(*out.shape)
+        rc = lib.svr_zarr_decode_chunks(
+            n, None, off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nbytes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+            int(zstd), int(crc), self.dtype.itemsize, cs, out.ctypes.data, strides, shape,
+            origin.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), fill.ctypes.data, _threads())
+        if rc < 0:
+            raise RuntimeError("the zstd codec needs libzstd, which was not found on this machine")
+        if rc > 0:
+            bad = tuple(int(v) for v in idx[rc - 1])
+            raise ValueError(f"chunk {bad} of {self.path} is corrupt (crc32c mismatch, corrupt zstd frame or wrong size)")
+        return out
 
     def __array__(self, dtype=None, copy=None):
         a = self[(slice(None),) * self.ndim]
@@ -414,13 +541,12 @@ def create_group(path: str, attributes=None) -> ZarrV3Group:
     return ZarrV3Group(path)
 
 
-def write_array(path: str, array, chunks, shards=None, compressor: str | None = "zstd", fill_value=0,
-                index_location: str = "end", separator: str = "/", skip_fill_chunks: bool = True) -> ZarrV3Array:
-    """Store ``array`` as a zarr v3 array: ``chunks`` (inner chunk shape), optional ``shards`` (outer chunk shape,
-    a multiple of ``chunks``), ``compressor`` in {None, "gzip", "zstd"} — with shards this is the layout of
-    ``group.create_array(name, shape, chunks=(16,16,16), shards=(64,64,64))`` in the reference's builders."""
-    a = np.asarray(array)
-    dtype = a.dtype
+def create_array(path: str, shape, dtype, chunks, shards=None, compressor: str | None = "zstd", fill_value=0,
+                 index_location: str = "end", separator: str = "/") -> "ZarrV3Array":
+    """Write the metadata of an EMPTY zarr v3 array (every chunk missing = fill value) and open it: the layout of
+    ``group.create_array(name, shape, chunks=(16,16,16), shards=(64,64,64))`` in the reference's builders
+    (scripts/create_mouse_multiscale.py:102-131).  Fill it with :func:`write_block`."""
+    dtype = np.dtype(dtype)
     names = {v: k for k, v in _DTYPES.items()}
     data_type = names[dtype.str.lstrip("<>|=")] if dtype.kind != "b" else "bool"
     chunks = tuple(int(c) for c in chunks)
@@ -441,7 +567,7 @@ def write_array(path: str, array, chunks, shards=None, compressor: str | None = 
         outer = shards
     else:
         codecs, outer = inner_codecs, chunks
-    meta = {"zarr_format": 3, "node_type": "array", "shape": list(a.shape), "data_type": data_type,
+    meta = {"zarr_format": 3, "node_type": "array", "shape": [int(v) for v in shape], "data_type": data_type,
             "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": list(outer)}},
             "chunk_key_encoding": {"name": "default", "configuration": {"separator": separator}},
             "fill_value": fill_value if not isinstance(fill_value, float) or np.isfinite(fill_value) else "NaN",
@@ -449,49 +575,98 @@ def write_array(path: str, array, chunks, shards=None, compressor: str | None = 
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "zarr.json"), "w") as f:
         json.dump(meta, f)
-    inner_chain = _Chain(inner_codecs, dtype, chunks)
-    fill = np.array(fill_value).astype(dtype)[()]
+    return ZarrV3Array(path)
 
-    def padded(lo, shape):
-        block = np.full(shape, fill, dtype)
-        hi = [min(l + s, n) for l, s, n in zip(lo, shape, a.shape)]
-        if all(h > l for l, h in zip(lo, hi)):
-            block[tuple(slice(0, h - l) for l, h in zip(lo, hi))] = a[tuple(slice(l, h) for l, h in zip(lo, hi))]
-        return block
 
-    grid = [-(-n // o) for n, o in zip(a.shape, outer)]
-    for oidx in product(*[range(g) for g in grid]):
-        olo = [i * o for i, o in zip(oidx, outer)]
-        key = "c" + "".join(separator + str(i) for i in oidx)
-        file = os.path.join(path, *key.split("/"))
-        if shards is None:
-            block = padded(olo, chunks)
-            if skip_fill_chunks and np.all(block == fill):
+def write_block(arr: "ZarrV3Array", outer_index, block, skip_fill_chunks: bool = True) -> int:
+    """Store ``block`` — the data of the outer chunk (shard, or plain chunk) at grid position ``outer_index``, clipped to
+    the array (``block.shape <= outer chunk shape``; what lies beyond it is padded with the fill value) — as that
+    chunk's file.  Inner chunks are encoded by ``host_codecs.c`` (all of a shard in one call) where it knows the codec
+    chain, else in Python.  Returns the bytes written (0: nothing but fill values, no file)."""
+    outer = arr._outer
+    sh = arr._chain.shard
+    chunks = arr.chunks
+    inner_chain = sh["chain"] if sh else arr._chain
+    dtype = arr.dtype
+    block = np.ascontiguousarray(block, dtype)
+    if block.ndim != arr.ndim or any(b > o for b, o in zip(block.shape, outer)):
+        raise ValueError("the block does not fit the outer chunk")
+    fill = np.asarray(arr.fill_value, dtype).reshape(1)
+    file = arr._file(tuple(int(i) for i in outer_index))
+    per = tuple(o // c for o, c in zip(outer, chunks))
+    grid = list(product(*[range(p) for p in per]))
+    native = _native_tail(inner_chain) if arr.ndim == 3 else None
+    lib = _host_codecs()
+    encoded = {}
+    if native is not None and lib is not None and arr.native:
+        zstd, crc = native
+        level = 3
+        for c in inner_chain.tail:
+            if c["name"] == "zstd":
+                level = int(c.get("configuration", {}).get("level", 3))
+        keep = [i for i in grid if all(ii * c < b for ii, c, b in zip(i, chunks, block.shape))]
+        n = len(keep)
+        if n:
+            raw = int(np.prod(chunks)) * dtype.itemsize
+            slot = int(lib.svr_zarr_encode_bound(raw, int(zstd)))
+            if slot == 0:
+                raise RuntimeError("the zstd codec needs libzstd, which was not found on this machine")
+            out = np.empty(n * slot, np.uint8)
+            sizes = np.zeros(n, np.uint64)
+            corner = np.ascontiguousarray(np.asarray(keep, np.int32) * np.asarray(chunks, np.int32))
+            rc = lib.svr_zarr_encode_chunks(
+                n, block.ctypes.data, (ctypes.c_int32 * 3)(*block.shape), corner.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                dtype.itemsize, (ctypes.c_int32 * 3)(*chunks), fill.ctypes.data, int(zstd), level, int(crc), int(skip_fill_chunks),
+                out.ctypes.data, slot, sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _threads(reading=False))
+            if rc != 0:
+                raise RuntimeError(f"svr_zarr_encode_chunks failed ({rc})")
+            for k, i in enumerate(keep):
+                if sizes[k]:
+                    encoded[i] = out[k * slot:k * slot + int(sizes[k])].tobytes()
+    else:
+        for i in grid:
+            lo = [ii * c for ii, c in zip(i, chunks)]
+            if any(l >= b for l, b in zip(lo, block.shape)):
                 continue
-            os.makedirs(os.path.dirname(file), exist_ok=True)
-            with open(file, "wb") as f:
-                f.write(inner_chain.encode_block(block))
-            continue
-        per = tuple(o // c for o, c in zip(outer, chunks))
+            piece = np.full(chunks, fill[0], dtype)
+            hi = [min(l + c, b) for l, c, b in zip(lo, chunks, block.shape)]
+            piece[tuple(slice(0, h - l) for l, h in zip(lo, hi))] = block[tuple(slice(l, h) for l, h in zip(lo, hi))]
+            if skip_fill_chunks and np.all(piece == fill[0]):
+                continue
+            encoded[i] = inner_chain.encode_block(piece)
+    if not encoded:
+        return 0
+    os.makedirs(os.path.dirname(file), exist_ok=True)
+    if sh is None:
+        data = encoded[grid[0]]
+    else:
         index = np.full(per + (2,), _EMPTY, np.uint64)
-        body = bytearray()
         index_len = 16 * int(np.prod(per)) + 4
-        base = index_len if index_location == "start" else 0
-        for iidx in product(*[range(p) for p in per]):
-            lo = [o + i * c for o, i, c in zip(olo, iidx, chunks)]
-            if any(l >= n for l, n in zip(lo, a.shape)):
-                continue
-            block = padded(lo, chunks)
-            if skip_fill_chunks and np.all(block == fill):
-                continue
-            enc = inner_chain.encode_block(block)
-            index[iidx] = (base + len(body), len(enc))
-            body += enc
-        if not len(body):
-            continue
+        base = 0 if sh["at_end"] else index_len
+        body = bytearray()
+        for i in grid:
+            if i in encoded:
+                index[i] = (base + len(body), len(encoded[i]))
+                body += encoded[i]
         raw_index = index.astype("<u8").tobytes()
         raw_index += struct.pack("<I", crc32c(raw_index))
-        os.makedirs(os.path.dirname(file), exist_ok=True)
-        with open(file, "wb") as f:
-            f.write(raw_index + bytes(body) if index_location == "start" else bytes(body) + raw_index)
-    return ZarrV3Array(path)
+        data = bytes(body) + raw_index if sh["at_end"] else raw_index + bytes(body)
+    with open(file, "wb") as f:
+        f.write(data)
+    arr._index_cache.pop(file, None)
+    arr._cache.clear()
+    return len(data)
+
+
+def write_array(path: str, array, chunks, shards=None, compressor: str | None = "zstd", fill_value=0,
+                index_location: str = "end", separator: str = "/", skip_fill_chunks: bool = True) -> ZarrV3Array:
+    """Store ``array`` as a zarr v3 array: ``chunks`` (inner chunk shape), optional ``shards`` (outer chunk shape,
+    a multiple of ``chunks``), ``compressor`` in {None, "gzip", "zstd"} — with shards this is the layout of
+    ``group.create_array(name, shape, chunks=(16,16,16), shards=(64,64,64))`` in the reference's builders."""
+    a = np.asarray(array)
+    arr = create_array(path, a.shape, a.dtype, chunks, shards, compressor, fill_value, index_location, separator)
+    outer = arr._outer
+    for oidx in product(*[range(-(-n // o)) for n, o in zip(a.shape, outer)]):
+        lo = [i * o for i, o in zip(oidx, outer)]
+        write_block(arr, oidx, a[tuple(slice(l, l + o) for l, o in zip(lo, outer))], skip_fill_chunks)
+    return arr

@@ -89,3 +89,43 @@ def test_kernel_source_hash_covers_the_march_sources_and_traffic_is_stamped():
 def test_summarise():
     s = bench.summarise([3.0, 1.0, 2.0])
     assert s == {"n": 3, "median_ms": 2.0, "min_ms": 1.0, "max_ms": 3.0}
+
+
+def test_config4_corridor_store_holds_exactly_what_the_flythrough_reads(tmp_path):
+    """bench.py --config C4 --source zarr3 at a rehearsal size: the sparse zarr v3 store written during setup holds
+    every voxel any `center_on_position` window of the path can request (equal to the lazily generated volume there),
+    and nothing but the shards those windows touch."""
+    import __graft_entry__ as g
+    from sub_volume_renderer_amd import Roi, SubVolume, SubVolumeMaterial, zarr3
+
+    g.build_synth()
+    g.build_host_codecs()
+    n = 1024
+    spec = bench.config4_spec(n, 320, 200)
+    spec.ring_shapes = [(9, 9, 4), (10, 9, 4), (9, 10, 3)]       # small windows keep this test to a few seconds
+    poses = bench.flythrough_poses(spec, 12, step=9.0)
+    positions = [spec.cam_position] + [eye for eye, _ in poses]
+    touched = bench.corridor_shards(spec, positions)
+    assert all(len(t) > 0 for t in touched)
+    arrays, stats = bench.write_corridor_store(str(tmp_path / "store"), n, 4096, touched)
+    assert stats["shards"] == 2 * sum(len(t) for t in touched) and 0 < stats["bytes_on_disk"] < stats["raw_bytes"]
+    assert sorted(zarr3.open_group(str(tmp_path / "store" / "raw.zarr")).keys()) == ["scale0", "scale1", "scale2"]
+    lazy = spec.pairs
+    plan = SubVolume(SubVolumeMaterial(lmip_threshold=1.0), list(lazy), list(spec.ring_shapes), list(spec.chunk_shapes))
+    for pos in (positions[0], positions[5], positions[-1]):
+        p = (plan.world.inverse_matrix @ np.array([*pos, 1.0]))[:3][::-1]
+        for lod, b in enumerate(plan.wrapping_buffers):
+            size = tuple((k - 1) * c for k, c in zip(b.shape_in_chunks, b.chunk_shape_in_pixels))
+            roi = b.get_snapped_roi_in_pixels(Roi(tuple(int(c * f - s // 2) for c, s, f in zip(p, size, b.scale_factor)), size))
+            roi = roi.intersect(Roi((0, 0, 0), lazy[lod][0].shape))
+            # one slab of the window per axis, as a ring reload would ask for it
+            for axis in range(3):
+                lo, hi = list(roi.begin), list(roi.end)
+                hi[axis] = min(hi[axis], lo[axis] + (16 if axis < 2 else 48))
+                sl = tuple(slice(int(a), int(c)) for a, c in zip(lo, hi))
+                np.testing.assert_array_equal(arrays[lod][0][sl], lazy[lod][0][sl])
+                np.testing.assert_array_equal(arrays[lod][1][sl], lazy[lod][1][sl])
+    # sparse: a shard far from the corridor is not stored and reads as the fill value
+    far = next(i for i in [(0, 0, 0), (n // 64 - 1,) * 3] if i not in touched[0])
+    assert not os.path.exists(arrays[0][0]._file(far))
+    assert not arrays[0][0][far[0] * 64:far[0] * 64 + 8, far[1] * 64:far[1] * 64 + 8, far[2] * 64:far[2] * 64 + 8].any()
