@@ -191,7 +191,7 @@ def write_corridor_store(root, n, n_labels, touched, shard=64, chunk=16):
 
     from sub_volume_renderer_amd import synth, zarr3
 
-    t0 = time.time()
+    t0 = last = time.time()
     stats = {"shards": 0, "bytes_on_disk": 0, "raw_bytes": 0}
     groups = {"raw": zarr3.create_group(os.path.join(root, "raw.zarr")), "labels": zarr3.create_group(os.path.join(root, "labels.zarr"))}
     arrays = []
@@ -219,6 +219,10 @@ def write_corridor_store(root, n, n_labels, touched, shard=64, chunk=16):
                     stats["shards"] += 2
                 stats["raw_bytes"] += d.nbytes + l.nbytes
                 k = j + 1
+                if time.time() - last > 30.0:            # a sign of life on long setups
+                    last = time.time()
+                    print(f"[bench] writing the corridor store: level {lod}, {stats['shards']} shard files, "
+                          f"{stats['raw_bytes'] / 1e9:.2f} GB of voxels so far ({last - t0:.0f} s)", file=sys.stderr, flush=True)
         arrays.append((zarr3.open_zarr(dens.path), zarr3.open_zarr(labs.path)))
     stats["write_seconds"] = round(time.time() - t0, 2)
     return arrays, stats
@@ -322,6 +326,7 @@ def main():
             spec.material.update(lmip_threshold=spec.material["lmip_threshold"] * scale16, clim=(0.0, 255.0 * scale16))
     t_gen = time.time() - t0
     spec.ring_storage = args.ring_storage
+
     def source_stats(reset=False):
         """(seconds inside the backing arrays' reads, decoded bytes handed out, stored bytes read) since the last reset:
         the lazy generator keeps them on its class, a zarr array on each instance."""
@@ -333,7 +338,7 @@ def main():
                     if reset:
                         a.read_seconds, a.read_bytes, a.stored_bytes = 0.0, 0, 0
         if reset:
-            source_stats(reset=True)
+            synth.LazyLod.read_seconds, synth.LazyLod.read_bytes = 0.0, 0
         return sec, dec, sto
 
     source_stats(reset=True)

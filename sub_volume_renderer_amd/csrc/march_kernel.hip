@@ -1089,7 +1089,13 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     int lx = live ? min((int)ex.x, (int)ex.y) : big, hx = live ? max((int)ex.x, (int)ex.y) : -big;
                     int ly = live ? min((int)ey.x, (int)ey.y) : big, hy = live ? max((int)ey.x, (int)ey.y) : -big;
                     int lz = live ? min((int)ez.x, (int)ez.y) : big, hz = live ? max((int)ez.x, (int)ez.y) : -big;
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_NO_BOX_REDUCE)
+                    // ablation (wrong pixels): lane 0's box stands for the wave's — the six DPP reductions are gone
+                    lx = __builtin_amdgcn_readfirstlane(lx); ly = __builtin_amdgcn_readfirstlane(ly); lz = __builtin_amdgcn_readfirstlane(lz);
+                    hx = lx + 12; hy = ly + 10; hz = lz + 10;
+#else
                     wave_min3_max3(lx, ly, lz, hx, hy, hz);
+#endif
                     if (COUNT) ++c_slabs;
                     lap(8);
                     if (lx == big) { run = 0; break; }                   // no live lane left
@@ -1123,6 +1129,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t plane_bytes = (uint32_t)(pz << 4);
                     const uint32_t zpitch = L.ring[1] * L.rx4;                       // bytes per ring z plane
                     lap(9);
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_NO_BRICK_LOADS)
+                    // ablation (wrong pixels): everything of a slab but the LDS-DMA loads themselves — what ANY reduction of
+                    // their number or bytes (shared boxes, loader waves) could gain at most (tools/exp_ablate.sh)
+                    if (false)
+#endif
                     for (int yc = 0; yc < ny; yc += rows_per) {
                         const int yy = yc + ly_lane;
                         uint32_t wy = (uint32_t)(ly + yy + L.addw[1]);
