@@ -87,6 +87,8 @@ def parse():
                          "zstd zarr v3 store of the fly-through's corridor (16^3 chunks in 64^3 shards, the layout of the reference's "
                          "builders), written to local disk during setup and read back through sub_volume_renderer_amd.zarr3; "
                          "synth: lazy arrays that generate every block on demand from the closed form (no store)")
+    ap.add_argument("--pace-hz", type=float, default=240.0,
+                    help="C4: also run the fly-through with frames released at this rate, like a display (0: skip), reported as `paced`")
     ap.add_argument("--store-dir", default=None, help="C4 --source zarr3: where to write the store (default: a fresh directory under $TMPDIR)")
     return ap.parse_args()
 
@@ -679,9 +681,10 @@ def main():
         path_steps = [instrumented(c)["steps"] for c in cams[args.warmup:]]
         loop = harness.loop(1)
 
-        def fly(mode, asynchronous):
+        def fly(mode, asynchronous, pace_hz=0.0):
             """Back to the start, W untimed frames, then K timed ones; per-frame wall times (frame k = enqueue the render,
-            move the ring windows while it runs, wait for it as a display would)."""
+            move the ring windows while it runs, wait for it as a display would).  `pace_hz` > 0: frames are released at
+            that rate, like a display's refresh (the wait for the next slot is not part of a frame's time)."""
             set_mode(mode == "full")
             vol.poll_uploads(wait=True)
             vol.center_on_position(poses[0][0])                            # blocking: rings as at the start
@@ -706,6 +709,8 @@ def main():
                 torch.cuda.current_stream(dev).synchronize()                   # (the order of the reference's do_draw:
                 if k >= args.warmup:                                           #  scripts/multi_scale.py:76-80), then wait for the frame
                     times.append((time.perf_counter() - t) * 1e3)
+                if pace_hz > 0.0:
+                    time.sleep(max(0.0, t + 1.0 / pace_hz - time.perf_counter()))
             torch.cuda.synchronize()
             if collective:
                 dist.barrier()
@@ -719,7 +724,8 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt = float(tt.item())
             a = np.sort(np.asarray(times))
-            return dict(dt=dt, frame_ms={"median": float(np.median(a)), "p99": float(a[min(len(a) - 1, int(0.99 * len(a)))]),
+            need = (ub / max(1, len(times) + args.warmup))                    # bytes the windows asked for per frame
+            return dict(dt=dt, pace_hz=pace_hz, bytes_per_frame=need, frame_ms={"median": float(np.median(a)), "p99": float(a[min(len(a) - 1, int(0.99 * len(a)))]),
                                          "max": float(a[-1]), "mean": float(a.mean()), "over_5ms": int((a > 5.0).sum())},
                         upload={"staged_bytes": ub, "seconds_in_upload_calls": round(us, 4),
                                 "GBps": (ub / us / 1e9) if us > 0 else None,
@@ -733,6 +739,11 @@ def main():
         runs = {"full": fly("full", True)}
         if "lmip" in modes:
             runs["lmip"] = fly("lmip", True)
+        if args.pace_hz > 0:
+            # the same path released at a display's rate: what the streaming front-end is for.  Unpaced, the march outruns
+            # any source (several hundred frames per second ask for GB/s of new chunks) and superseded requests are
+            # dropped; paced, every load should land before the next window move asks for more
+            runs["paced"] = fly("lmip" if "lmip" in modes else "full", True, pace_hz=args.pace_hz)
         if args.blocking_too:
             runs["full_blocking"] = fly("full", False)
         if rank == 0:
@@ -760,11 +771,25 @@ def main():
             }
             if store:
                 result["store"] = store
-            for name in ("lmip", "full_blocking"):
+            for name in ("lmip", "full_blocking", "paced"):
                 if name in runs:
                     q = runs[name]
                     result[name] = {"frames_per_s": steps / q["dt"], "ms_per_step": q["dt"] / steps * 1e3,
                                     "frame_ms": q["frame_ms"], "upload": q["upload"]}
+            if "paced" in runs:
+                q = runs["paced"]
+                result["paced"].update(
+                    march_mode="lmip" if "lmip" in modes else "full", pace_hz=q["pace_hz"],
+                    what="the same fly-through with frames released at a display's refresh rate (the wait for the next slot is not "
+                         "part of frame_ms): the load the asynchronous streaming path is built for")
+            # what the unpaced path asks of its source: new ring bytes per frame x the frame rate it reaches
+            src_rate = r["upload"]["source_read_GBps"]
+            result["streaming_demand"] = {
+                "ring_bytes_per_frame": r["bytes_per_frame"],
+                "needed_source_GBps_at_the_unpaced_rate": r["bytes_per_frame"] * (steps / r["dt"]) / 1e9,
+                "source_GBps": src_rate,
+                "frames_per_s_the_source_can_feed": (src_rate * 1e9 / r["bytes_per_frame"]) if (src_rate and r["bytes_per_frame"]) else None,
+                "note": "staged bytes only count loads that were not superseded: the true demand of the unpaced path is higher"}
         counts = {"full": {"steps": int(np.mean(path_steps)), "hits": 0, "frags": 0}}
 
     # ---- CPU baseline: the oracle (a port: the reference itself cannot run offline) on a bounded sample
