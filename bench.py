@@ -691,6 +691,8 @@ def main():
             vol.synchronize()
             upload_stats(reset=True)
             source_stats(reset=True)
+            for b in vol.wrapping_buffers:
+                b.superseded_requests = 0
             times = []
             if collective:
                 dist.barrier()
@@ -715,6 +717,8 @@ def main():
             if collective:
                 dist.barrier()
             dt = time.perf_counter() - t_start
+            if pace_hz > 0.0:
+                time.sleep(1.0 / pace_hz)                                      # the last frame's own requests get one slot too
             landed = vol.poll_uploads(wait=False)
             vol.poll_uploads(wait=True)
             ub, us = upload_stats()
@@ -734,7 +738,10 @@ def main():
                                 "source_read_seconds": round(src[0], 3),
                                 "source_read_GBps": (src[1] / src[0] / 1e9) if src[0] else None,          # decoded bytes handed to the rings
                                 "source_stored_GBps": (src[2] / src[0] / 1e9) if (src[0] and src[2]) else None,   # compressed bytes read from disk
-                                "all_loads_landed_at_last_frame": bool(landed)})
+                                "all_loads_landed_at_last_frame": bool(landed),
+                                # window moves that were asked for while a level was still loading and were replaced by a later
+                                # one before they started (the latest wins): 0 = every requested window was loaded
+                                "requests_superseded": int(sum(b.superseded_requests for b in vol.wrapping_buffers))})
 
         runs = {"full": fly("full", True)}
         if "lmip" in modes:

@@ -185,6 +185,7 @@ class WrappingBuffer:
 
         self._roi_px: Roi | None = None
         self._pending_async = None
+        self.superseded_requests = 0                     # asynchronous requests that were replaced by a later one before they started
         self._wanted_roi = None          # newest request that arrived while an asynchronous load was in flight
         self._async_owner = None         # weakref to the SubVolume whose upload worker serves this buffer
         self._current_logical_roi_in_chunks: Roi | None = None
@@ -307,6 +308,8 @@ class WrappingBuffer:
         the request is only remembered (the latest one wins) and replayed by :meth:`finish_async_load`.
         """
         if self._pending_async is not None:
+            if getattr(self, "_wanted_roi", None) is not None:
+                self.superseded_requests += 1            # an older remembered request is dropped unserved (the latest wins)
             self._wanted_roi = logical_roi_in_pixels
             return None
         self._wanted_roi = None
