@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
                     help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
+    ap.add_argument("--float32-block", action="store_true", help="C5: measure the float32-ring block too (C2 does by default)")
     ap.add_argument("--no-float32-block", action="store_true",
                     help="C2 / C5 at N = 1 with native rings: skip the second measurement of the same workload on float32 rings "
                          "(the reference's own layout, _wrapping_buffer.py:50-53), reported as `float32_rings`")
@@ -650,6 +651,7 @@ def main():
         # _wrapping_buffer.py:50-53; its pyramid builders write float32 sources, create_mouse_multiscale.py:82), where the
         # 4 B per ray-step of SURVEY.md 8d are the bytes really stored
         if (world == 1 and not collective and not args.no_float32_block and args.ring_storage == "native"
+                and (cfg == "C2" or args.float32_block)      # C5 on float32 rings (19 GB, the 4-GiB build of the kernel) only on request
                 and args.source_dtype == "uint8" and vol._rings.density_storage != "float32"):
             spec32 = (config5_spec if cfg == "C5" else config2_spec)(n, W, H, camera, pairs)
             spec32.ring_storage = "float32"
@@ -739,9 +741,9 @@ def main():
                                 "source_read_GBps": (src[1] / src[0] / 1e9) if src[0] else None,          # decoded bytes handed to the rings
                                 "source_stored_GBps": (src[2] / src[0] / 1e9) if (src[0] and src[2]) else None,   # compressed bytes read from disk
                                 "all_loads_landed_at_last_frame": bool(landed),
-                                # window moves that were asked for while a level was still loading and were replaced by a later
-                                # one before they started (the latest wins): 0 = every requested window was loaded
-                                "requests_superseded": int(sum(b.superseded_requests for b in vol.wrapping_buffers))})
+                                # chunk windows that were asked for while a level was still loading and were replaced by a request
+                                # for a DIFFERENT window before they started (the latest wins): 0 = every window asked for was loaded
+                                "windows_superseded": int(sum(b.superseded_requests for b in vol.wrapping_buffers))})
 
         runs = {"full": fly("full", True)}
         if "lmip" in modes:

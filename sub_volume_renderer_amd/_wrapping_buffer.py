@@ -308,8 +308,9 @@ class WrappingBuffer:
         the request is only remembered (the latest one wins) and replayed by :meth:`finish_async_load`.
         """
         if self._pending_async is not None:
-            if getattr(self, "_wanted_roi", None) is not None:
-                self.superseded_requests += 1            # an older remembered request is dropped unserved (the latest wins)
+            older = getattr(self, "_wanted_roi", None)
+            if older is not None and self.get_snapped_roi_in_pixels(older) != self.get_snapped_roi_in_pixels(logical_roi_in_pixels):
+                self.superseded_requests += 1            # a remembered request for ANOTHER chunk window is dropped unserved (the latest wins)
             self._wanted_roi = logical_roi_in_pixels
             return None
         self._wanted_roi = None
