@@ -635,13 +635,6 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const float dx = (P.xdir[0] - ncx * P.xdir[3]) * (float)P.frame.frame_w;
         const float dy = (P.xdir[1] - ncy * P.xdir[3]) * (float)P.frame.frame_h;
         if (P.orient && fabsf(dy) > fabsf(dx)) { lr = lane & ((64 >> lw) - 1); lc = lane >> (6 - lw); }
-        // orient 2 (8 x 8 tiles): lanes in Z order — a lane-quad is a 2 x 2 pixel block.  Where the volume's x axis lies
-        // along the view rather than across the screen, neither screen direction keeps a quad inside one row of voxels;
-        // a 2 x 2 block then spans fewer (y, z) rows than four pixels in a line
-        if (P.orient == 2 && lw == 3) {
-            lc = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
-            lr = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-        }
     }
     const int c = c0 + lc;
     const int r = r0 + lr;

@@ -905,7 +905,6 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
     P.brick_lines = ((c->variant >> 16) & 0xFF) ? ((c->variant >> 16) & 0xFF) : 32;
     P.orient = (c->variant & 1024) ? 0 : 1;
-    if (svr_exp_env_int("SVR_LANE_MAP", 0) == 2) P.orient = 2;          // A/B (-DSVR_EXPERIMENTS builds): Z-order lanes everywhere
     P.dbg_nowait = ((c->variant & SVR_EXP_VARIANT_BITS) >> 11) & 3;      // -DSVR_EXPERIMENTS builds: bit 11 no brick wait, bit 12 skip the march loop
     P.brick_lod_mask = ((c->variant >> 24) & 0xFF) ? ((c->variant >> 24) & 0xFF) : 0xFF;
     const int brick_mask = P.brick_lod_mask;
