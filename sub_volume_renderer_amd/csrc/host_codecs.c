@@ -113,12 +113,20 @@ static void* pool_worker(void* p) {
     return NULL;
 }
 
+/* A forked child inherits the pool's bookkeeping but none of its threads: start over there. */
+static void pool_after_fork_in_child(void) {
+    pthread_mutex_init(&pool.mu, NULL); pthread_mutex_init(&pool.job_mu, NULL);
+    pthread_cond_init(&pool.wake, NULL); pthread_cond_init(&pool.done, NULL);
+    pool.nthreads = 0; pool.active = 0; pool.want = 0;
+}
+
 /* run fn(item, worker, arg) for item in [0, n) on up to nthreads threads (worker ids 0 .. nthreads - 1; 0 = the caller) */
 static void pool_run(int n, int nthreads, pool_fn fn, void* arg) {
     if (nthreads > POOL_MAX) nthreads = POOL_MAX;
     if (nthreads > n) nthreads = n;
     if (nthreads <= 1) { for (int k = 0; k < n; ++k) fn(k, 0, arg); return; }
     pthread_mutex_lock(&pool.job_mu);
+    if (!pool.init) { pool.init = 1; pthread_atfork(NULL, NULL, pool_after_fork_in_child); }
     pthread_mutex_lock(&pool.mu);
     while (pool.nthreads < nthreads - 1) {
         const int id = pool.nthreads + 1;

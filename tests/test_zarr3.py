@@ -251,3 +251,23 @@ def test_create_array_and_write_block_make_a_sparse_store(tmp_path):
     want = np.zeros((70, 64, 6), np.uint8)
     want[3:67] = block[:, :, 58:64]
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.skipif(not _native_built(), reason="libsvr_hostcodec.so not built")
+def test_native_reader_survives_a_fork(tmp_path, monkeypatch):
+    """The decoder's thread pool does not exist in a forked child (threads are not inherited): the child must build its
+    own instead of waiting for workers that are not there."""
+    monkeypatch.setenv("SVR_ZARR_THREADS", "4")
+    a = np.random.default_rng(8).integers(0, 255, (96, 80, 64)).astype(np.uint8)
+    z = zarr3.write_array(str(tmp_path / "a"), a, (16, 16, 16), (32, 32, 32))
+    np.testing.assert_array_equal(z[:, :, :], a)               # the parent's pool exists now
+    pid = os.fork()
+    if pid == 0:
+        try:
+            ok = np.array_equal(z[:, :, :], a)
+        except BaseException:
+            ok = False
+        os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    np.testing.assert_array_equal(z[3:, :, 5:], a[3:, :, 5:])
