@@ -88,7 +88,7 @@ def parse():
                          "zstd zarr v3 store of the fly-through's corridor (16^3 chunks in 64^3 shards, the layout of the reference's "
                          "builders), written to local disk during setup and read back through sub_volume_renderer_amd.zarr3; "
                          "synth: lazy arrays that generate every block on demand from the closed form (no store)")
-    ap.add_argument("--pace-hz", type=float, default=240.0,
+    ap.add_argument("--pace-hz", type=float, default=120.0,
                     help="C4: also run the fly-through with frames released at this rate, like a display (0: skip), reported as `paced`")
     ap.add_argument("--store-dir", default=None, help="C4 --source zarr3: where to write the store (default: a fresh directory under $TMPDIR)")
     return ap.parse_args()
