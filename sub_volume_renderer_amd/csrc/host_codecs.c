@@ -325,3 +325,115 @@ int svr_zarr_encode_chunks(int n, const uint8_t* src, const int32_t src_shape[3]
     for (int w = 0; w < POOL_MAX; ++w) { free(j.blk[w]); if (j.ctx[w]) z_free_cctx(j.ctx[w]); }
     return atomic_load(&j.rc);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * A whole read request in one call: the inner chunks are handed over in GROUPS, each group = the chunks of the request that
+ * live in one file (a shard, or a plain chunk file when chunks_per_shard == 0), at most a few dozen per group so that
+ * the groups spread over the pool.  Per group: open the file, read and verify the shard index (little-endian u64
+ * (offset, nbytes) pairs [+ crc32c]), read the span that holds the group's chunks with one pread, then check / decompress /
+ * place every chunk.  A missing file or an index entry of 2^64 - 1 is the fill value.
+ * Returns 0, -1 without libzstd, -2 for an I/O or index error (bad_out = the group), or 1 + k for the first corrupt
+ * chunk k (position in the request's chunk list).
+ * --------------------------------------------------------------------------------------------------------------- */
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+typedef struct {
+    const char* const* paths; const int32_t* grp_first; const int32_t* within; int chunks_per_shard, index_at_end, index_crc;
+    decode_job dec;                       /* base = NULL: off[] / nbytes[] are filled here per chunk */
+    uint64_t* off; uint64_t* nbytes;
+    uint8_t* span[POOL_MAX]; size_t span_cap[POOL_MAX];
+    atomic_int io_error; atomic_ullong stored;
+} read_job;
+
+static int pread_all(int fd, void* buf, size_t n, off_t at) {
+    uint8_t* p = (uint8_t*)buf;
+    while (n) {
+        const ssize_t got = pread(fd, p, n, at);
+        if (got < 0 && errno == EINTR) continue;
+        if (got <= 0) return -1;
+        p += got; n -= (size_t)got; at += got;
+    }
+    return 0;
+}
+
+static void read_group(int g, int worker, void* arg) {
+    read_job* j = (read_job*)arg;
+    const int k0 = j->grp_first[g], k1 = j->grp_first[g + 1];
+    if (k1 <= k0) return;
+    const int fd = open(j->paths[g], O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        if (errno != ENOENT) { atomic_store(&j->io_error, g + 1); return; }
+        for (int k = k0; k < k1; ++k) { j->off[k] = UINT64_MAX; decode_one(k, worker, &j->dec); }      /* not stored */
+        return;
+    }
+    struct stat st;
+    int ok = fstat(fd, &st) == 0;
+    uint64_t lo = UINT64_MAX, hi = 0;
+    if (ok && j->chunks_per_shard == 0) {                                     /* a plain chunk file: the file is the chunk */
+        j->off[k0] = 0; j->nbytes[k0] = (uint64_t)st.st_size; lo = 0; hi = (uint64_t)st.st_size;
+        ok = k1 == k0 + 1;
+    } else if (ok) {
+        const size_t ilen = (size_t)16 * j->chunks_per_shard + (j->index_crc ? 4 : 0);
+        uint64_t stack_index[2 * 512];
+        uint64_t* index = ilen <= sizeof(stack_index) ? stack_index : (uint64_t*)malloc(ilen);
+        ok = index && (size_t)st.st_size >= ilen && pread_all(fd, index, ilen, j->index_at_end ? st.st_size - (off_t)ilen : 0) == 0;
+        if (ok && j->index_crc) {
+            uint32_t want; memcpy(&want, (uint8_t*)index + ilen - 4, 4);
+            ok = svr_crc32c(index, ilen - 4, 0) == want;
+        }
+        for (int k = k0; ok && k < k1; ++k) {
+            const uint64_t o = index[2 * j->within[k]], nb = index[2 * j->within[k] + 1];
+            j->off[k] = o; j->nbytes[k] = nb;
+            if (o == UINT64_MAX && nb == UINT64_MAX) continue;
+            if (o > (uint64_t)st.st_size || nb > (uint64_t)st.st_size - o) { ok = 0; break; }
+            if (o < lo) lo = o;
+            if (o + nb > hi) hi = o + nb;
+        }
+        if (index != stack_index) free(index);
+    }
+    if (ok && hi > lo) {
+        const size_t need = (size_t)(hi - lo);
+        if (j->span_cap[worker] < need) {
+            free(j->span[worker]);
+            j->span_cap[worker] = need + need / 2 + 4096;
+            j->span[worker] = (uint8_t*)malloc(j->span_cap[worker]);
+            if (!j->span[worker]) { j->span_cap[worker] = 0; ok = 0; }
+        }
+        ok = ok && pread_all(fd, j->span[worker], need, (off_t)lo) == 0;
+        if (ok) atomic_fetch_add(&j->stored, (unsigned long long)need);
+    }
+    close(fd);
+    if (!ok) { atomic_store(&j->io_error, g + 1); return; }
+    for (int k = k0; k < k1; ++k) {
+        if (j->off[k] != UINT64_MAX) j->off[k] = (uint64_t)(uintptr_t)(j->span[worker] + (j->off[k] - lo));     /* address (base = NULL) */
+        decode_one(k, worker, &j->dec);
+    }
+}
+
+int svr_zarr_read_groups(int ngroups, const char* const* paths, const int32_t* grp_first, const int32_t* within,
+                         int chunks_per_shard, int index_at_end, int index_crc, int zstd, int crc, int elem,
+                         const int32_t chunk[3], uint8_t* dst, const int64_t dst_strides[3], const int32_t dst_shape[3],
+                         const int32_t* origin, const void* fill, int nthreads, uint64_t* stored_bytes, int* bad_group) {
+    if (zstd && zstd_bind() != 1) return -1;
+    const int n = grp_first[ngroups];
+    read_job j;
+    memset(&j, 0, sizeof(j));
+    j.paths = paths; j.grp_first = grp_first; j.within = within;
+    j.chunks_per_shard = chunks_per_shard; j.index_at_end = index_at_end; j.index_crc = index_crc;
+    j.off = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    j.nbytes = (uint64_t*)calloc((size_t)(n > 0 ? n : 1), sizeof(uint64_t));
+    if (!j.off || !j.nbytes) { free(j.off); free(j.nbytes); return -2; }
+    decode_job d = { NULL, j.off, j.nbytes, zstd, crc, elem, chunk, dst, dst_strides, dst_shape, origin, fill,
+                     (size_t)chunk[0] * chunk[1] * chunk[2] * (size_t)elem, { 0 }, { 0 }, 0 };
+    j.dec = d;
+    pool_run(ngroups, nthreads < 1 ? 1 : nthreads, read_group, &j);
+    for (int w = 0; w < POOL_MAX; ++w) { free(j.dec.tmp[w]); if (j.dec.ctx[w]) z_free_dctx(j.dec.ctx[w]); free(j.span[w]); }
+    free(j.off); free(j.nbytes);
+    if (stored_bytes) *stored_bytes = (uint64_t)atomic_load(&j.stored);
+    const int io = atomic_load(&j.io_error);
+    if (io) { if (bad_group) *bad_group = io - 1; return -2; }
+    return atomic_load(&j.dec.bad);
+}

@@ -110,6 +110,11 @@ def _host_codecs():
             lib.svr_zarr_decode_chunks.restype = ctypes.c_int
             lib.svr_zarr_decode_chunks.argtypes = [ctypes.c_int, vp, u64p, u64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, vp,
                                                    ctypes.POINTER(ctypes.c_int64), i32p, i32p, vp, ctypes.c_int]
+            lib.svr_zarr_read_groups.restype = ctypes.c_int
+            lib.svr_zarr_read_groups.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), i32p, i32p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, vp,
+                                                 ctypes.POINTER(ctypes.c_int64), i32p, i32p, vp, ctypes.c_int, u64p,
+                                                 ctypes.POINTER(ctypes.c_int)]
             lib.svr_zarr_encode_bound.restype = ctypes.c_size_t
             lib.svr_zarr_encode_bound.argtypes = [ctypes.c_size_t, ctypes.c_int]
             lib.svr_zarr_encode_chunks.restype = ctypes.c_int
@@ -420,9 +425,11 @@ class ZarrV3Array:
         return out[tuple(0 if s else slice(None) for s in squeeze)]
 
     def _read_native(self, lo, hi) -> np.ndarray:
-        """The box [lo, hi) through ``svr_zarr_decode_chunks``: per shard file ONE open, the index (cached) and the byte
-        ranges of the inner chunks the box touches; then every chunk of the request is checked (crc32c), decompressed
-        (zstd) and placed by a team of threads in one call."""
+        """The box [lo, hi) through ``host_codecs.c``.  Stores with the usual shard index (little-endian u64 pairs
+        [+ crc32c]) and plain chunk files take ``svr_zarr_read_groups``: ONE call for the whole request — the pool's
+        threads open the files, read and verify the shard indexes, read the byte ranges and check (crc32c), decompress
+        (zstd) and place every inner chunk.  Other index codecs: the files are read here and only the chunks go to
+        ``svr_zarr_decode_chunks``."""
         lib = _host_codecs()
         zstd, crc = self._native_codecs
         c = self.chunks
@@ -442,6 +449,13 @@ class ZarrV3Array:
         order = np.argsort(key, kind="stable")
         _, starts = np.unique(key[order], return_index=True)
         bounds = list(starts) + [n]
+        # the whole request in ONE native call when the shard index is what the reference's stores have (little-endian
+        # u64 pairs [+ crc32c]): files are opened, indexed and read by the pool's threads too
+        index_names = [c["name"] for c in sh["index_codecs"]] if sh else ["bytes"]
+        index_little = all(c.get("configuration", {}).get("endian", "little") == "little" for c in (sh["index_codecs"] if sh else []) if c["name"] == "bytes")
+        if index_names in (["bytes"], ["bytes", "crc32c"]) and index_little and n < 2 ** 31:
+            return self._read_native_groups(lib, lo, hi, idx, origin, outer, within, per, order, bounds, zstd, crc,
+                                            "crc32c" in index_names)
         pieces, total = [], 0
         for g in range(len(starts)):
             members = order[bounds[g]:bounds[g + 1]]
@@ -489,6 +503,44 @@ class ZarrV3Array:
             raise RuntimeError("the zstd codec needs libzstd, which was not found on this machine")
         if rc > 0:
             bad = tuple(int(v) for v in idx[rc - 1])
+            raise ValueError(f"chunk {bad} of {self.path} is corrupt (crc32c mismatch, corrupt zstd frame or wrong size)")
+        return out
+
+    def _read_native_groups(self, lib, lo, hi, idx, origin, outer, within, per, order, bounds, zstd, crc, index_crc):
+        sh = self._chain.shard
+        c = self.chunks
+        n = len(order)
+        paths, first = [], [0]
+        for g in range(len(bounds) - 1):
+            a, b = int(bounds[g]), int(bounds[g + 1])
+            path = self._file(tuple(int(v) for v in outer[order[a]])).encode()
+            for q in range(a, b, 24):                           # <= 24 chunks per group: the groups spread over the pool
+                paths.append(path)
+                first.append(min(b, q + 24))
+        ng = len(paths)
+        c_paths = (ctypes.c_char_p * ng)(*paths)
+        grp_first = np.asarray(first, np.int32)
+        w = within[order]
+        within_lin = np.ascontiguousarray((w[:, 0] * per[1] + w[:, 1]) * per[2] + w[:, 2], np.int32)
+        origin_sorted = np.ascontiguousarray(origin[order])
+        out = np.empty([h - l for l, h in zip(lo, hi)], self.dtype)
+        fill = np.asarray(self.fill_value, self.dtype).reshape(1)
+        stored, bad_group = ctypes.c_uint64(0), ctypes.c_int(-1)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        rc = lib.svr_zarr_read_groups(
+            ng, c_paths, grp_first.ctypes.data_as(i32p), within_lin.ctypes.data_as(i32p),
+            int(np.prod(per)) if sh else 0, int(sh["at_end"]) if sh else 0, int(index_crc) if sh else 0,
+            int(zstd), int(crc), self.dtype.itemsize, (ctypes.c_int32 * 3)(*c), out.ctypes.data,
+            (ctypes.c_int64 * 3)(*out.strides), (ctypes.c_int32 * 3)(*out.shape), origin_sorted.ctypes.data_as(i32p),
+            fill.ctypes.data, _threads(), ctypes.byref(stored), ctypes.byref(bad_group))
+        self.stored_bytes += int(stored.value)
+        if rc == -1:
+            raise RuntimeError("the zstd codec needs libzstd, which was not found on this machine")
+        if rc == -2:
+            raise ValueError(f"{paths[bad_group.value].decode()}: unreadable, shorter than its shard index says, or its index fails "
+                             "its crc32c")
+        if rc > 0:
+            bad = tuple(int(v) for v in idx[order[rc - 1]])
             raise ValueError(f"chunk {bad} of {self.path} is corrupt (crc32c mismatch, corrupt zstd frame or wrong size)")
         return out
 

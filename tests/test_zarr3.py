@@ -271,3 +271,26 @@ def test_native_reader_survives_a_fork(tmp_path, monkeypatch):
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     np.testing.assert_array_equal(z[3:, :, 5:], a[3:, :, 5:])
+
+
+@pytest.mark.skipif(not _native_built(), reason="libsvr_hostcodec.so not built")
+def test_native_reader_reports_damaged_shards(tmp_path):
+    """A truncated shard (shorter than its index says) and a shard whose index fails its crc32c: the request raises and
+    names the file; a missing shard is not an error (fill value)."""
+    a = np.random.default_rng(9).integers(1, 255, (128, 64, 64)).astype(np.uint8)
+    root = str(tmp_path / "a")
+    z = zarr3.write_array(root, a, (16, 16, 16), (64, 64, 64), fill_value=0)
+    np.testing.assert_array_equal(z[:, :, :], a)
+    first, second = os.path.join(root, "c", "0", "0", "0"), os.path.join(root, "c", "1", "0", "0")
+    raw = open(first, "rb").read()
+    open(first, "wb").write(raw[:len(raw) // 2] + raw[-(16 * 64 + 4):])          # body cut short, index intact
+    with pytest.raises(ValueError, match="c/0/0/0"):
+        zarr3.ZarrV3Array(root)[0:64, :, :]
+    np.testing.assert_array_equal(zarr3.ZarrV3Array(root)[64:128, :, :], a[64:128])     # the other shard still reads
+    raw2 = bytearray(open(second, "rb").read())
+    raw2[-10] ^= 1                                                                 # inside the index
+    open(second, "wb").write(bytes(raw2))
+    with pytest.raises(ValueError, match="c/1/0/0"):
+        zarr3.ZarrV3Array(root)[64:128, :, :]
+    os.remove(second)
+    assert not zarr3.ZarrV3Array(root)[64:128, :, :].any()
