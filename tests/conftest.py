@@ -19,6 +19,8 @@ def _built():
 
     g.build_hip()
     g.build_oracle()
+    g.build_host_codecs()          # the native half of the zarr v3 reader (gcc): its tests skip themselves without it
+    g.build_synth()
 
 
 def _has_gpu() -> bool:
