@@ -309,6 +309,11 @@ def main():
             positions = [spec.cam_position] + [eye for eye, _ in flythrough_poses(spec, args.warmup + steps)]
             touched = corridor_shards(spec, positions)
             root = args.store_dir or tempfile.mkdtemp(prefix="svr_c4_store_")
+            if not args.store_dir:                               # a store of our own making (0.5 GB): gone when the bench ends
+                import atexit
+                import shutil
+
+                atexit.register(shutil.rmtree, root, ignore_errors=True)
             arrays, store = write_corridor_store(root, n, n_labels, touched)
             store["path"] = root
             spec.pairs = arrays                              # zarr arrays as backing data, as the reference is fed (README.md:18)
