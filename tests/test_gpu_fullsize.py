@@ -136,6 +136,39 @@ def test_c2_oracle_parity_on_sampled_rows(c2, mode):
     assert rep["total_steps"] > 30_000_000
 
 
+@pytest.mark.parametrize("view", ["K2", "-y", "diag"])
+def test_c2_other_views_oracle_parity_on_sampled_rows(c2, view):
+    """The same full-size volume from inside (K2), along the y axis and along the space diagonal — the views whose waves
+    take other paths than K1's (gathers only, long brick slabs, wrap events): every 60th row of the 1080p frame, both
+    kernels, LMIP mode, against the oracle fed with the rings read back from HBM."""
+    vol, W, H = c2.volume, 1920, 1080
+    vol.material.lmip_threshold = 0.5 * 255.0
+    n = 1024
+    spec = c2.spec
+    keep = (spec.cam_position, spec.cam_target)
+    try:
+        if view == "K2":
+            centre = np.array([(n - 1) / 2.0] * 3)
+            eye = centre + np.array([0.1 * n, 0.05 * n, -0.2 * n])
+            spec.cam_position, spec.cam_target = tuple(eye), tuple(eye + np.array([0.6, 0.3, 0.74]))
+        else:
+            d = np.array({"-y": (0.02, -1, 0.03), "diag": (-1, -1, -1)}[view], float)
+            d /= np.linalg.norm(d)
+            c = (n - 1) / 2.0
+            spec.cam_position, spec.cam_target = tuple(np.array([c, c, c]) + 1.6 * n * d), (c, c, c)
+        cam = spec.camera()
+        if "rings" not in c2.__dict__:
+            c2.__dict__["rings"] = _rings_from_device(vol)
+        sample = FrameRegion(0, 0, W, 18, 1, 60)
+        m = dict(spec.material)
+        m["lmip_threshold"] = 0.5 * 255.0
+        ref = lmip.render(c2.rings, spec.matrices(), tuple(float(v) for v in vol._volume_dimensions), m, W, H, region=sample)
+        rep = testing.hold_both_to(ref, vol, cam, W, H, region=sample)
+        assert rep["n_hit"] > 1000 and rep["total_steps"] > 5_000_000
+    finally:
+        spec.cam_position, spec.cam_target = keep
+
+
 def test_one_rank_rccl_pipeline_equals_single_gpu_frame():
     """bench.py's N > 1 pipeline on real RCCL in a one-rank process group (own process: the group and the
     library state stay out of this one): row bands, asynchronous gather of device tensors on four streams,
