@@ -301,3 +301,42 @@ def test_native_reader_reports_damaged_shards(tmp_path):
         zarr3.ZarrV3Array(root)[64:128, :, :]
     os.remove(second)
     assert not zarr3.ZarrV3Array(root)[64:128, :, :].any()
+
+
+# ---------------------------------------------------------------------------------------------------
+# property test (the reference's own wrapping-buffer tests use hypothesis the same way, FUTURE.md:210-216)
+# ---------------------------------------------------------------------------------------------------
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+
+@pytest.mark.skipif(not _native_built(), reason="libsvr_hostcodec.so not built")
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(data=st.data())
+def test_any_box_of_any_store_reads_back_what_was_written(tmp_path_factory, data):
+    """Random array shapes, chunk / shard shapes, dtypes, codecs, index locations, fill values and request boxes: the
+    native reader, the Python reader and numpy slicing of the source agree."""
+    shape = tuple(data.draw(st.integers(1, 40)) for _ in range(3))
+    chunks = tuple(data.draw(st.sampled_from([1, 2, 3, 4, 8])) for _ in range(3))
+    sharded = data.draw(st.booleans())
+    shards = tuple(c * data.draw(st.integers(1, 3)) for c in chunks) if sharded else None
+    dtype = data.draw(st.sampled_from([np.uint8, np.uint16, np.uint32, np.float32]))
+    compressor = data.draw(st.sampled_from(["zstd", None]))
+    fill = data.draw(st.sampled_from([0, 3]))
+    loc = data.draw(st.sampled_from(["end", "start"]))
+    seed = data.draw(st.integers(0, 2 ** 16))
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 6, shape).astype(dtype)                  # few distinct values: some chunks are all fill
+    a[rng.random(shape) < 0.5] = fill
+    root = str(tmp_path_factory.mktemp("z") / "a")
+    z = zarr3.write_array(root, a, chunks, shards, compressor=compressor, fill_value=fill, index_location=loc)
+    lo = [data.draw(st.integers(0, n - 1)) for n in shape]
+    hi = [data.draw(st.integers(l + 1, n)) for l, n in zip(lo, shape)]
+    sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+    z.native = True
+    fast = z[sl]
+    z.native = False
+    z._cache.clear()
+    slow = z[sl]
+    np.testing.assert_array_equal(fast, a[sl])
+    np.testing.assert_array_equal(slow, a[sl])
