@@ -832,10 +832,14 @@ static int tile_order_by_cost_for(svr_ctx* c, const MarchParams& P, int tile_w, 
 // every render takes the straightforward kernel's 64-bit addressing.
 static bool span_addressable(const svr_ctx* c) {
     const uint64_t des = svr_dtype_size(c->density_storage);
-    for (int l = 0; l < c->num_lods; ++l)
-        if ((uint64_t)c->lod[l].voxels * des + 64 >= ((uint64_t)1 << 32) ||
+    for (int l = 0; l < c->num_lods; ++l) {
+        // (a ring of 4 GiB or more is reached through two resources split at a z plane: both parts must stay below 4 GiB)
+        const uint64_t plane = (uint64_t)c->lod[l].ring[0] * (uint64_t)c->lod[l].ring[1] * des;
+        const uint64_t zsplit = plane ? std::min<uint64_t>((uint64_t)c->lod[l].ring[2], (((uint64_t)1 << 32) - 128) / plane) : 0;
+        if (zsplit == 0 || ((uint64_t)c->lod[l].ring[2] - zsplit) * plane + 64 >= ((uint64_t)1 << 32) ||
             (uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
             (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
+    }
     return true;
 }
 
@@ -1031,9 +1035,19 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.density_all_bytes = P.per_lod_rsrc ? 0u : (uint32_t)c->density_all_bytes;
     for (int l = 0; l < c->num_lods; ++l) {
         LodParams& Q = P.lod[l];
+        Q.rbase_hi = nullptr; Q.rbytes_hi = 0u; Q.zsplit = Q.ring[2];
         if (P.per_lod_rsrc) {
+            const uint64_t des64 = svr_dtype_size(c->density_storage);
+            const uint64_t plane = (uint64_t)Q.ring[0] * (uint64_t)Q.ring[1] * des64, bytes = (uint64_t)c->lod[l].voxels * des64;
             Q.rbase = c->lod[l].density; Q.base_bytes = 0u;
-            Q.rbytes = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)c->lod[l].voxels * svr_dtype_size(c->density_storage) + 64);
+            if (bytes + 64 < ((uint64_t)1 << 32)) {
+                Q.rbytes = (uint32_t)(bytes + 64);
+            } else {                                         // two resources, split at a ring z plane (span_addressable checked the sizes)
+                Q.zsplit = (uint32_t)std::min<uint64_t>((uint64_t)Q.ring[2], (((uint64_t)1 << 32) - 128) / plane);
+                Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
+                Q.rbase_hi = static_cast<const char*>(c->lod[l].density) + (uint64_t)Q.zsplit * plane;
+                Q.rbytes_hi = (uint32_t)(bytes - (uint64_t)Q.zsplit * plane + 64);
+            }
         } else {
             Q.rbase = c->density_all; Q.rbytes = P.density_all_bytes;
         }

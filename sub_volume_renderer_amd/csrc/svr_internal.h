@@ -50,6 +50,12 @@ struct LodParams {
     // below 4 GiB (one resource serves every lane of a mixed-LOD gather), else this LOD's ring alone
     const void* rbase;
     uint32_t rbytes;
+    // a ring of 4 GiB or more (float voxels of a 2048^3-class volume) is addressed through TWO resources: ring planes
+    // [0, zsplit) through (rbase, rbytes), planes [zsplit, ring z) through (rbase_hi, rbytes_hi), offsets relative to each
+    // (zsplit = ring z and rbytes_hi = 0 where one resource reaches the whole ring)
+    const void* rbase_hi;
+    uint32_t rbytes_hi;
+    uint32_t zsplit;
     uint32_t cell_base;        // byte offset of the LOD's cell grid
     uint32_t cdim[3];          // cells per axis
     int32_t  cshift;           // log2 of the cell size (3 or 2)
