@@ -247,3 +247,35 @@ def compare(res: RenderResult, ref) -> dict:
         out["steps_equal"] = bool(np.array_equal(res.steps.cpu().numpy().view(np.uint32), ref.steps))
         out["total_steps"] = int(ref.steps.astype(np.int64).sum())
     return out
+
+
+# ---------------------------------------------------------------------------
+def single_voxel_spec(offset_xyz=(0, 5, 0), size: int = 33, frame: int = 65, distance: float = 80.0) -> SceneSpec:
+    """A known-answer scene whose picture can be derived by hand (no oracle, no shared matrices): one bright voxel in a
+    volume of zeros, ``offset_xyz`` voxels (shader order) away from the volume's centre, seen by a camera on the +x
+    axis that looks at the centre down -x with +y up.  pygfx / three.js conventions (camera looks along its local -z,
+    right-handed, NDC y up, pixel rows top to bottom): local x = y_cam x z_cam = (0,1,0) x (1,0,0) = -z_world, so the
+    voxel must appear ``offset z`` columns LEFT and ``offset y`` rows ABOVE the centre pixel, scaled by the pixel's
+    footprint: the field of view spans the mean of width and height, i.e. 2 * distance * tan(fov / 2) world units over
+    ``frame`` pixels at the volume's centre."""
+    c = size // 2
+    data = np.zeros((size, size, size), np.float32)
+    seg = np.zeros((size, size, size), np.uint32)
+    x, y, z = c + offset_xyz[0], c + offset_xyz[1], c + offset_xyz[2]
+    data[z, y, x] = 200.0                                       # numpy [a0, a1, a2] = texel (x = a2, y = a1, z = a0)
+    seg[z, y, x] = 7
+    return SceneSpec(
+        pairs=[(data, seg)], chunk_shapes=[(size, size, size)], ring_shapes=[(1, 1, 1)],
+        material=dict(lmip_threshold=100.0, fog_density=0.0, colors=[(0.0, 1.0, 1.0)] * 8, clim=(0.0, 200.0)),
+        width=frame, height=frame, cam_position=(c + distance, float(c), float(c)), cam_target=(float(c), float(c), float(c)),
+        fov=45.0, depth_range=(1.0, 1000.0), centers=[((float(c), float(c), float(c)), [(size, size, size)])])
+
+
+def expected_single_voxel_pixel(offset_xyz=(0, 5, 0), frame: int = 65, distance: float = 80.0, fov: float = 45.0):
+    """(row, column) of the pixel that must show the voxel of :func:`single_voxel_spec` (derivation in its docstring;
+    the voxel's distance from the camera is ``distance - offset x``)."""
+    per_pixel = 2.0 * np.tan(np.radians(fov) / 2.0) / frame     # world units per pixel at unit distance
+    depth = distance - offset_xyz[0]
+    col = (frame - 1) / 2.0 - offset_xyz[2] / (depth * per_pixel)
+    row = (frame - 1) / 2.0 - offset_xyz[1] / (depth * per_pixel)
+    return row, col

@@ -316,3 +316,19 @@ def test_pick_plane_matches_oracle(simple):
     res2 = vol.render(scene.camera, scene.width, scene.height)
     torch.cuda.synchronize()
     assert torch.equal(res2.label, res.label) and torch.equal(res2.rgba, res.rgba)
+
+
+@pytest.mark.parametrize("offset", [(0, 5, 0), (0, 0, 5), (6, 4, -9)])
+def test_single_voxel_lands_where_the_camera_conventions_say(offset):
+    """The hand-derived end-to-end known answer of tests/test_oracle_lmip.py on the device: where one bright voxel must
+    appear on screen follows from the camera conventions alone (no oracle, no shared matrices)."""
+    spec = testing.single_voxel_spec(offset)
+    scene = testing.build(spec)
+    prod, inst = testing.render_both(scene.volume, scene.camera, scene.width, scene.height)
+    want_row, want_col = testing.expected_single_voxel_pixel(offset)
+    for r in (prod, inst):
+        rows, cols = np.nonzero(r.flags.cpu().numpy() == 2)
+        assert rows.size >= 1
+        assert abs(rows.mean() - want_row) <= 0.75 and abs(cols.mean() - want_col) <= 0.75, (rows, cols, want_row, want_col)
+        assert np.all(r.label_numpy()[r.flags.cpu().numpy() == 2] == 7)
+    check(scene)                                                  # and the oracle agrees pixel for pixel

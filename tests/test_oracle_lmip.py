@@ -292,3 +292,21 @@ def test_weighted_average_prefers_near_structures():
     hi = lmip.render_spec(spec).rgba[centre][..., 0]
     assert np.all((lo > 0.05) & (lo < 0.6))                # 8 of ~32 voxels along the ray are bright
     assert hit.sum() > 100 and not np.allclose(lo, hi)
+
+
+@pytest.mark.parametrize("offset", [(0, 0, 0), (0, 5, 0), (0, 0, 5), (0, -7, 3), (6, 4, -9)])
+def test_single_voxel_lands_where_the_camera_conventions_say(offset):
+    """End-to-end known answer that does not go through matrices shared with the product: one bright voxel, a camera
+    on the +x axis; where it must appear on screen follows from the conventions alone (testing.single_voxel_spec).
+    A flipped y, a mirrored x, a wrong field-of-view rule or a half-pixel shift would move it."""
+    r = lmip.render_spec(testing.single_voxel_spec(offset))
+    rows, cols = np.nonzero(r.flags == 2)
+    assert rows.size >= 1
+    want_row, want_col = testing.expected_single_voxel_pixel(offset)
+    # the voxel is one unit wide, a pixel 1.02 units at the centre plane: the hits form a blob of <= 3 x 3 pixels around it
+    assert abs(rows.mean() - want_row) <= 0.75 and abs(cols.mean() - want_col) <= 0.75, (rows, cols, want_row, want_col)
+    assert rows.max() - rows.min() <= 2 and cols.max() - cols.min() <= 2
+    assert np.all(r.label[r.flags == 2] == 7)
+    # depth: the voxel's centre through proj * cam * world as fs_main.wgsl:61-72 writes it: (coord - 0.5) is a NORMALISED
+    # coordinate there, so the depth belongs to a point next to the volume's origin corner: only its range is checked here
+    assert np.all((r.depth[r.flags == 2] > 0) & (r.depth[r.flags == 2] < 1))
