@@ -602,11 +602,15 @@ def main():
             if "lmip" in m["kms"]:
                 a_lmip = algo_bytes(counts["lmip"], npix) / (m["kms"]["lmip"] * 1e-3) / 1e9
                 # NOT a roofline fraction: skipped iterations are charged 4 B each without moving a byte
+                lmip_entry = (pmc_entry(ring_storage)[0] or {}).get("lmip")
                 blk["lmip"]["kernel"] = {"kernel_ms": m["kms"]["lmip"], "ref_equiv_GBps": a_lmip,
                                          "ref_equiv_frac": a_lmip / HBM_PEAK_GBS,
                                          "note": "reference-equivalent bytes (4 B per executed iteration, SURVEY.md 8d) per second "
                                                  "over the HBM peak; the kernel skips most iterations without a fetch, so this is no "
                                                  "measure of memory use and can exceed 1: compare kernel_ms"}
+                if lmip_entry:                                  # what the counters of LMIP-only frames show (same stamp as `traffic`)
+                    blk["lmip"]["kernel"]["traffic"] = lmip_entry.get("traffic_bytes_per_launch")
+                    blk["lmip"]["kernel"]["binding"] = lmip_entry.get("binding")
         return blk
 
     result = None

@@ -19,11 +19,11 @@ prof, out = sys.argv[1], sys.argv[2]
 command = " ".join(sys.argv[3:])
 
 
-def mean_counter(name, pat="8, false,"):        # the production build of march_span (not the instrumented <..., true, ...> one)
+def mean_counter(name, pat="8, false,", passes="pmc_*"):        # the production build of march_span (not the instrumented <..., true, ...> one)
     vals = []
     # (the full-mode passes only: the LMIP-only passes live in lmip_pmc_* beside them — round 2's glob took those in too,
     # 5 LMIP dispatches among 60)
-    for f in glob.glob(os.path.join(prof, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(prof, passes, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == name and pat in r["Kernel_Name"]:
@@ -85,6 +85,25 @@ if insts_valu and act_valu and gui:
         "wave_residency": {"waiting_share": (wait_any / wave_cycles) if wave_cycles and wait_any else None},
         "SQ_INSTS_VALU": insts_valu, "SQ_ACTIVE_INST_VALU": act_valu, "GRBM_GUI_ACTIVE": gui,
         "TA_BUSY_avr": ta_busy, "TCP_PENDING_STALL_CYCLES_sum": tcp_stall,
+    }
+# ---- the same for LMIP-only frames (tools/prof_driver.py lmip: the north_star workload), when those passes exist
+lm = {k: mean_counter(k, passes="lmip_pmc_*")[0] for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TA_BUSY_avr",
+                                                            "TCP_PENDING_STALL_CYCLES_sum", "FETCH_SIZE", "WRITE_SIZE")}
+if lm["SQ_ACTIVE_INST_VALU"] and lm["GRBM_GUI_ACTIVE"]:
+    cyc = lm["GRBM_GUI_ACTIVE"] / 8.0
+    cand = {"valu_issue": 4.0 * lm["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc)}
+    if lm["TA_BUSY_avr"]:
+        cand["ta_address_path"] = lm["TA_BUSY_avr"] / cyc
+    if lm["TCP_PENDING_STALL_CYCLES_sum"]:
+        cand["l1_miss_stall"] = lm["TCP_PENDING_STALL_CYCLES_sum"] / (CUS * cyc)
+    top = max(cand, key=cand.get)
+    traffic_lmip = int((lm["FETCH_SIZE"] or 0) * 1024 * 2 + (lm["WRITE_SIZE"] or 0) * 1024) if lm["FETCH_SIZE"] else None
+    doc["lmip"] = {
+        "command": "tools/prof_driver.py lmip 1024 12 0 K1 --ring-storage " + ("float32" if cfgd["ring_storage"] == "float32" else "native"),
+        "traffic_bytes_per_launch": traffic_lmip,
+        "binding": {"resource": top, "frac": cand[top], "insts": lm["SQ_INSTS_VALU"], "kernel_cycles": cyc,
+                    "busy_share": {k: round(v, 4) for k, v in cand.items()},
+                    "hbm_busy_share": round(traffic_lmip / (cyc / 2.4e9) / 8e12, 4) if traffic_lmip else None},
     }
 with open(out, "w") as f:
     json.dump(doc, f, indent=1)

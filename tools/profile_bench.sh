@@ -27,6 +27,9 @@ for ST in $STORAGES; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lmip -- $DRV > $OUT/trace_lmip.log 2>&1 || echo "lmip trace pass failed"
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_SQ -- $DRV > $OUT/lmip_pmc_SQ.log 2>&1 || echo "lmip pmc pass failed"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_FETCH -- $DRV > $OUT/lmip_pmc_FETCH.log 2>&1 || echo "lmip fetch pass failed"
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_WRITE -- $DRV > $OUT/lmip_pmc_WRITE.log 2>&1 || echo "lmip write pass failed"
+  timeout -k 10 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_TA -- $DRV > $OUT/lmip_pmc_TA.log 2>&1 || echo "lmip TA pass failed"
+  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-include-regex march --output-format csv -d $OUT/lmip_pmc_GRBM -- $DRV > $OUT/lmip_pmc_GRBM.log 2>&1 || echo "lmip GRBM pass failed"
   grep -h '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
   echo "=== ring storage $ST: $CMD" > $OUT/summary.txt
   python3 $ROOT/tools/pmc_summary.py $OUT march_span >> $OUT/summary.txt 2>&1
@@ -37,7 +40,7 @@ for ST in $STORAGES; do
   f2=$(find $OUT/trace_lmip -name "*kernel_stats.csv" | head -1); [ -n "$f2" ] && { echo "--- LMIP mode ($DRV)" >> $OUT/summary.txt; head -1 $f2 > $OUT/kernel_stats_march_lmip.csv; grep march_ $f2 >> $OUT/kernel_stats_march_lmip.csv; cat $OUT/kernel_stats_march_lmip.csv >> $OUT/summary.txt; }
   python3 - >> $OUT/summary.txt 2>&1 <<PY
 import csv, glob
-for d in ("lmip_pmc_SQ", "lmip_pmc_FETCH"):
+for d in ("lmip_pmc_SQ", "lmip_pmc_FETCH", "lmip_pmc_WRITE", "lmip_pmc_TA", "lmip_pmc_GRBM"):
     acc = {}
     for f in glob.glob("$OUT/" + d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
