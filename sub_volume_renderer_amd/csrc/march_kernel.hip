@@ -429,10 +429,10 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, 
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
-// The same for a ring that is reached through two buffer resources (4 GiB or more: LodParams::zsplit): the offset is
-// relative to the part that holds the slot's z plane, `hi` says which
+// The same for a ring that is reached through several buffer resources (4 GiB or more: parts of LodParams::zsplit
+// planes): the offset is relative to the part that holds the slot's z plane, `part` says which
 template <int ESH, typename LodT>
-__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, bool& hi) {
+__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, uint32_t& part) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -440,9 +440,17 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, floa
     wx = min(wx, wx - L.ring[0]);
     wy = min(wy, wy - L.ring[1]);
     wz = min(wz, wz - L.ring[2]);
-    hi = wz >= L.zsplit;
-    wz = hi ? wz - L.zsplit : wz;
+    part = 0u;
+    for (uint32_t k = 1; k < L.nparts; ++k) part += wz >= k * L.zsplit ? 1u : 0u;         // nparts <= 8, wave-uniform
+    wz -= part * L.zsplit;
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
+}
+
+// the buffer resource of part p (wave-uniform) of such a ring
+template <typename LodT>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint32_t p) {
+    const char* base = static_cast<const char*>(L.rbase) + (size_t)p * (size_t)L.part_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(p + 1u == L.nparts ? L.rbytes_last : L.rbytes), 0x00020000);
 }
 
 // Raw texel as fetched: f32 rings (ESH = 2) hold the sample itself, u8 rings (ESH = 0) the byte,
@@ -604,8 +612,7 @@ struct LodK {
     int32_t  slab;
     const void* rbase;
     uint32_t rbytes;
-    const void* rbase_hi;      // rings of 4 GiB or more: planes [zsplit, ring z) (LodParams)
-    uint32_t rbytes_hi, zsplit;
+    uint32_t nparts, zsplit, part_bytes, rbytes_last;      // rings of 4 GiB or more: parts of zsplit planes (LodParams)
 };
 __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     LodK k;
@@ -615,7 +622,7 @@ __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     }
     k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
     k.rbase = p->lod[l].rbase; k.rbytes = p->lod[l].rbytes;
-    k.rbase_hi = p->lod[l].rbase_hi; k.rbytes_hi = p->lod[l].rbytes_hi; k.zsplit = p->lod[l].zsplit;
+    k.nparts = p->lod[l].nparts; k.zsplit = p->lod[l].zsplit; k.part_bytes = p->lod[l].part_bytes; k.rbytes_last = p->lod[l].rbytes_last;
     return k;
 }
 
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
                         Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << ESH) + L.base_bytes;  // mod 2^32
-                        if constexpr (BIG) zth = (int)L.zsplit - (int)kz;                 // slot plane ic_z + kz >= zsplit <=> ic_z >= zth
+                        if constexpr (BIG) zth = (int)L.zsplit - (int)kz;                 // slot plane ic_z + kz >= k * zsplit <=> ic_z >= zth + (k - 1) * zsplit
                         if (ev[l].cx > n) E = min(E, ev[l].cx);
                         if (ev[l].cy > n) E = min(E, ev[l].cy);
                         if (ev[l].cz > n) E = min(E, ev[l].cz);
@@ -954,17 +961,15 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
                         if (__builtin_amdgcn_ballot_w64(sel) != 0) {
                             const LodK Lg = load_lod(Pg, l);
-                            bool hi;
-                            const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, hi);
-                            __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
-                                const_cast<void*>(Lg.rbase), 0, (int)Lg.rbytes, 0x00020000);
-                            const texel_t t = fetch_density<ESH>(rl, (sel && !hi) ? ofs : 0xFFFFFFFFu);
-                            acc = (sel && !hi) ? t : acc;
-                            if (__builtin_amdgcn_ballot_w64(sel && hi) != 0) {        // the ring's upper part (4 GiB or more)
-                                __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-                                    const_cast<void*>(Lg.rbase_hi), 0, (int)Lg.rbytes_hi, 0x00020000);
-                                const texel_t th = fetch_density<ESH>(rh, (sel && hi) ? ofs : 0xFFFFFFFFu);
-                                acc = (sel && hi) ? th : acc;
+                            uint32_t part;
+                            const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, part);
+                            // (a ring of 4 GiB or more: one load per part that some lane's texel lies in)
+                            for (unsigned long long todo = __builtin_amdgcn_ballot_w64(sel); todo != 0ull;) {
+                                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
+                                const bool mine = sel && part == p;
+                                const texel_t t = fetch_density<ESH>(part_rsrc(Lg, p), mine ? ofs : 0xFFFFFFFFu);
+                                acc = mine ? t : acc;
+                                todo &= ~__builtin_amdgcn_ballot_w64(mine);
                             }
                         }
                         done = done || sel;
@@ -1003,10 +1008,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // the buffer resource this LOD's texels come through (hardware range check returns 0 beyond it)
             __amdgpu_buffer_rsrc_t rsrc = rsrc_all;
             if constexpr (BIG) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.rbase), 0, (int)L.rbytes, 0x00020000);
-            // (a ring of 4 GiB or more: its planes from L.zsplit on come through a second resource; rbytes_hi = 0 otherwise)
-            __amdgpu_buffer_rsrc_t rsrc_hi = rsrc;
-            if constexpr (BIG) rsrc_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.rbase_hi), 0, (int)L.rbytes_hi, 0x00020000);
-            const bool ring_split = BIG && L.rbytes_hi != 0u;            // wave-uniform
+            // (a ring of 4 GiB or more comes through nparts resources of L.zsplit planes each: part_rsrc)
+            const bool ring_split = BIG && L.nparts > 1u;                // wave-uniform
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
             // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
@@ -1176,11 +1179,13 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             for (int zz = 0; zz < nz; ++zz) {
                                 uint32_t wz = (uint32_t)(lz + zz + L.addw[2]);      // wave-uniform
                                 wz = min(wz, wz - L.ring[2]);
-                                if (BIG && ring_split && wz >= L.zsplit)             // this plane lives in the ring's upper part
+                                if (BIG && ring_split) {                             // the part this plane lives in
+                                    uint32_t p = 0u;
+                                    while (p + 1u < L.nparts && wz >= (p + 1u) * L.zsplit) ++p;
                                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                        rsrc_hi, (__attribute__((address_space(3))) void*)(lds_all + lds_chunk + zz * plane_bytes),
-                                        16, (int)(lane_src + (wz - L.zsplit) * zpitch), 0, 0, 0);
-                                else
+                                        part_rsrc(L, p), (__attribute__((address_space(3))) void*)(lds_all + lds_chunk + zz * plane_bytes),
+                                        16, (int)(lane_src + (wz - p * L.zsplit) * zpitch), 0, 0, 0);
+                                } else
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                     rsrc, (__attribute__((address_space(3))) void*)(lds_all + lds_chunk + zz * plane_bytes),
                                     16, (int)(lane_src + wz * zpitch), 0, 0, 0);
@@ -1249,22 +1254,28 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 for (int u = 0; u < U; ++u) s[u] = undefined_value<texel_t>();
                 if (BIG && ring_split) {
                     // a ring of 4 GiB or more: a lane's texel comes through the resource of the part that holds its plane
-                    // (offsets are mod 2^32 relative to the lower part: minus the lower part's size = relative to the upper)
-                    const uint32_t lower_bytes = L.zsplit * (L.ring[1] * L.rx4);
+                    // (offsets are mod 2^32 relative to part 0: minus p parts' sizes = relative to part p)
                     float2_t it2 = { (float)n, (float)n + 1.0f };
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
                         const float2_t cz = (it2 * Rtz + Rsz) * ssz;      // the z index of the pair again (this path is rare)
                         it2 += 2.0f;
-                        const bool h0 = (int)cz.x >= zth, h1 = (int)cz.y >= zth;
-                        texel_t a0 = fetch_density<ESH>(rsrc, (live && !h0) ? off[u] : 0xFFFFFFFFu);
-                        texel_t a1 = fetch_density<ESH>(rsrc, (live && !h1) ? off[u + 1] : 0xFFFFFFFFu);
-                        if (__builtin_amdgcn_ballot_w64(live && (h0 || h1)) != 0) {
-                            const texel_t b0 = fetch_density<ESH>(rsrc_hi, (live && h0) ? off[u] - lower_bytes : 0xFFFFFFFFu);
-                            const texel_t b1 = fetch_density<ESH>(rsrc_hi, (live && h1) ? off[u + 1] - lower_bytes : 0xFFFFFFFFu);
-                            a0 = h0 ? b0 : a0; a1 = h1 ? b1 : a1;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int icz = h ? (int)cz.y : (int)cz.x;
+                            uint32_t part = 0u;
+                            for (uint32_t k = 1; k < L.nparts; ++k) part += icz >= zth + (int)((k - 1u) * L.zsplit) ? 1u : 0u;
+                            const uint32_t rel = off[u + h] - part * L.part_bytes;
+                            texel_t a = 0;
+                            for (unsigned long long todo = __builtin_amdgcn_ballot_w64(live); todo != 0ull;) {
+                                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
+                                const bool mine = live && part == p;
+                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p), mine ? rel : 0xFFFFFFFFu);
+                                a = mine ? t : a;
+                                todo &= ~__builtin_amdgcn_ballot_w64(mine);
+                            }
+                            s[u + h] = a;
                         }
-                        s[u] = a0; s[u + 1] = a1;
                     }
                 } else
                 if (live) {

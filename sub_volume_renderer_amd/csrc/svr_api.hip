@@ -833,10 +833,10 @@ static int tile_order_by_cost_for(svr_ctx* c, const MarchParams& P, int tile_w, 
 static bool span_addressable(const svr_ctx* c) {
     const uint64_t des = svr_dtype_size(c->density_storage);
     for (int l = 0; l < c->num_lods; ++l) {
-        // (a ring of 4 GiB or more is reached through two resources split at a z plane: both parts must stay below 4 GiB)
+        // (a ring of 4 GiB or more is reached through up to 8 resources of whole z planes, each below 4 GiB: 32 GiB)
         const uint64_t plane = (uint64_t)c->lod[l].ring[0] * (uint64_t)c->lod[l].ring[1] * des;
         const uint64_t zsplit = plane ? std::min<uint64_t>((uint64_t)c->lod[l].ring[2], (((uint64_t)1 << 32) - 128) / plane) : 0;
-        if (zsplit == 0 || ((uint64_t)c->lod[l].ring[2] - zsplit) * plane + 64 >= ((uint64_t)1 << 32) ||
+        if (zsplit == 0 || ((uint64_t)c->lod[l].ring[2] + zsplit - 1) / zsplit > 8 ||
             (uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
             (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
     }
@@ -1035,18 +1035,18 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     P.density_all_bytes = P.per_lod_rsrc ? 0u : (uint32_t)c->density_all_bytes;
     for (int l = 0; l < c->num_lods; ++l) {
         LodParams& Q = P.lod[l];
-        Q.rbase_hi = nullptr; Q.rbytes_hi = 0u; Q.zsplit = Q.ring[2];
+        Q.nparts = 1u; Q.zsplit = Q.ring[2]; Q.part_bytes = 0u; Q.rbytes_last = 0u;
         if (P.per_lod_rsrc) {
             const uint64_t des64 = svr_dtype_size(c->density_storage);
             const uint64_t plane = (uint64_t)Q.ring[0] * (uint64_t)Q.ring[1] * des64, bytes = (uint64_t)c->lod[l].voxels * des64;
             Q.rbase = c->lod[l].density; Q.base_bytes = 0u;
             if (bytes + 64 < ((uint64_t)1 << 32)) {
-                Q.rbytes = (uint32_t)(bytes + 64);
-            } else {                                         // two resources, split at a ring z plane (span_addressable checked the sizes)
+                Q.rbytes = Q.rbytes_last = (uint32_t)(bytes + 64);
+            } else {                                         // parts of whole ring z planes (span_addressable checked the count)
                 Q.zsplit = (uint32_t)std::min<uint64_t>((uint64_t)Q.ring[2], (((uint64_t)1 << 32) - 128) / plane);
-                Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
-                Q.rbase_hi = static_cast<const char*>(c->lod[l].density) + (uint64_t)Q.zsplit * plane;
-                Q.rbytes_hi = (uint32_t)(bytes - (uint64_t)Q.zsplit * plane + 64);
+                Q.nparts = (uint32_t)(((uint64_t)Q.ring[2] + Q.zsplit - 1) / Q.zsplit);
+                Q.part_bytes = Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
+                Q.rbytes_last = (uint32_t)(bytes - (uint64_t)(Q.nparts - 1) * Q.part_bytes + 64);
             }
         } else {
             Q.rbase = c->density_all; Q.rbytes = P.density_all_bytes;

@@ -50,12 +50,14 @@ struct LodParams {
     // below 4 GiB (one resource serves every lane of a mixed-LOD gather), else this LOD's ring alone
     const void* rbase;
     uint32_t rbytes;
-    // a ring of 4 GiB or more (float voxels of a 2048^3-class volume) is addressed through TWO resources: ring planes
-    // [0, zsplit) through (rbase, rbytes), planes [zsplit, ring z) through (rbase_hi, rbytes_hi), offsets relative to each
-    // (zsplit = ring z and rbytes_hi = 0 where one resource reaches the whole ring)
-    const void* rbase_hi;
-    uint32_t rbytes_hi;
+    // a ring of 4 GiB or more (float voxels of a 2048^3-class volume) is addressed through `nparts` (<= 8) resources of
+    // `zsplit` ring z planes each (the last one holds the rest): part p starts at rbase + p * part_bytes and takes
+    // offsets relative to its own start; `rbytes` then is the size of a full part, `rbytes_last` that of the last one
+    // (nparts = 1, zsplit = ring z where one resource reaches the whole ring)
+    uint32_t nparts;
     uint32_t zsplit;
+    uint32_t part_bytes;
+    uint32_t rbytes_last;
     uint32_t cell_base;        // byte offset of the LOD's cell grid
     uint32_t cdim[3];          // cells per axis
     int32_t  cshift;           // log2 of the cell size (3 or 2)

@@ -388,12 +388,13 @@ def test_rings_of_4_gib_in_total_keep_the_span_kernel_with_one_resource_per_lod(
         _assert_frame(res, lmip.render_spec(small), "big rings, mip")
 
 
-def test_a_single_float_ring_of_4_gib_is_reached_through_two_resources():
-    """Two FLOAT32 rings of 1024 x 1024 x 1056 slots — 4.43 GB each, more than the 32-bit byte offsets of one buffer
-    resource reach (round 2 fell back to the one-fetch-per-step kernel here: config 5 on the reference's float layout).
-    The span kernel now addresses such a ring through two resources split at ring plane 992; the level-0 window is put
-    across that plane AND across the ring's wrap (planes 952 .. 1023, 0 .. 23), and the frame must equal the oracle's
-    from three views (gathers, brick slabs and general batches all cross the split)."""
+def test_a_single_float_ring_beyond_4_gib_is_reached_through_several_resources():
+    """A FLOAT32 ring of 1024 x 1024 x 2112 slots — 8.86 GB, more than the 32-bit byte offsets of one buffer resource
+    reach, or of two (round 2 fell back to the one-fetch-per-step kernel at 4 GiB: config 5 on the reference's float
+    layout).  The span kernel addresses such a ring through parts of whole z planes (here 496 + 496 + 32); the level-0
+    window is put across the boundary at plane 992 AND the ring's wrap (planes 952 .. 1023, 0 .. 23), then across the
+    boundary at plane 496, and every frame must equal the oracle's from three views (gathers, brick slabs and general
+    batches all cross the part boundaries), with both kernels."""
     import ctypes as C
 
     from sub_volume_renderer_amd import _native as N, synth
@@ -403,30 +404,36 @@ def test_a_single_float_ring_of_4_gib_is_reached_through_two_resources():
         d, l = synth.volume(64, k)
         pairs.append((np.tile(d, (17, 1, 1)), np.tile(l, (17, 1, 1))))           # (1088, 64, 64) and (544, 32, 32): long along a0 = z
     kw = dict(threshold=0.45, chunk_shapes=[(8, 8, 16), (4, 4, 16)])
-    spec = testing.synthetic_spec(64, 160, 96, pairs=pairs, ring_shapes=[(128, 128, 66), (256, 256, 66)], **kw)
+    spec = testing.synthetic_spec(64, 160, 96, pairs=pairs, ring_shapes=[(128, 128, 132), (40, 16, 4)], **kw)
     spec.ring_storage = "float32"
-    target = np.array([31.5, 31.5, 1000.0])                                        # shader order (x, y, z)
-    spec.centers = [(tuple(target), [(96, 32, 32), (64, 32, 32)])]                 # level 0: a0 in [952, 1048)
+    sizes = [(96, 32, 32), (64, 32, 32)]
     spec.depth_range = (0.2, 4000.0)
     small = testing.synthetic_spec(64, 160, 96, pairs=pairs, ring_shapes=[(16, 8, 4), (20, 8, 2)], **kw)
-    small.centers, small.depth_range = spec.centers, spec.depth_range
+    small.depth_range = spec.depth_range
+    spec.centers, small.centers = [], []
     scene = None
-    for view in ((-0.80, 0.36, 0.48), (0.05, 0.08, -1.0), (0.6, -0.3, 0.74)):
-        dvec = np.array(view) / np.linalg.norm(view)
-        spec.cam_position, spec.cam_target = tuple(target + 170.0 * dvec), tuple(target)
-        small.cam_position, small.cam_target = spec.cam_position, spec.cam_target
-        if scene is None:
-            scene = testing.build(spec)
-            assert scene.volume._rings.density_storage == "float32"
-            b0 = scene.volume.wrapping_buffers[0]
-            assert tuple(b0.shape_in_pixels) == (1024, 1024, 1056) and b0._current_logical_roi_in_pixels.begin[0] == 952
-        res = testing.render_both(scene.volume, spec.camera(), spec.width, spec.height)
-        census = (C.c_uint32 * 8)()
-        N.check(N.lib().svr_debug_counters(scene.volume._rings.handle, census, 1), "svr_debug_counters")
-        assert census[6] > 0, "the span kernel must run (the straightforward kernel keeps no census)"
-        ref = lmip.render_spec(small)
-        _assert_frame(res, ref, ("4 GiB float ring", view))
-        assert (ref.flags == 2).sum() > 200
+    for z_centre, first_plane in ((1000.0, 952), (498.0, 448)):
+        target = np.array([31.5, 31.5, z_centre])                                  # shader order (x, y, z)
+        spec.centers.append((tuple(target), sizes))
+        small.centers.append((tuple(target), sizes))
+        for view in ((-0.80, 0.36, 0.48), (0.05, 0.08, -1.0), (0.6, -0.3, 0.74)):
+            dvec = np.array(view) / np.linalg.norm(view)
+            spec.cam_position, spec.cam_target = tuple(target + 170.0 * dvec), tuple(target)
+            small.cam_position, small.cam_target = spec.cam_position, spec.cam_target
+            if scene is None:
+                scene = testing.build(spec)
+                assert scene.volume._rings.density_storage == "float32"
+                assert tuple(scene.volume.wrapping_buffers[0].shape_in_pixels) == (1024, 1024, 2112)
+            elif scene.volume.wrapping_buffers[0]._current_logical_roi_in_pixels.begin[0] != first_plane:
+                scene.volume.center_on_position(tuple(target), sizes)
+            assert scene.volume.wrapping_buffers[0]._current_logical_roi_in_pixels.begin[0] == first_plane
+            res = testing.render_both(scene.volume, spec.camera(), spec.width, spec.height)
+            census = (C.c_uint32 * 8)()
+            N.check(N.lib().svr_debug_counters(scene.volume._rings.handle, census, 1), "svr_debug_counters")
+            assert census[6] > 0, "the span kernel must run (the straightforward kernel keeps no census)"
+            ref = lmip.render_spec(small)
+            _assert_frame(res, ref, ("float ring beyond 4 GiB", z_centre, view))
+            assert (ref.flags == 2).sum() > 200
     scene.volume.close()
 
 
