@@ -1255,6 +1255,23 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 if (BIG && ring_split) {
                     // a ring of 4 GiB or more: a lane's texel comes through the resource of the part that holds its plane
                     // (offsets are mod 2^32 relative to part 0: minus p parts' sizes = relative to part p)
+                    // ic_z is monotone along a ray: the parts of a lane's first and last sample of the batch bound those of the
+                    // samples in between.  Nearly always every live lane's batch lies in ONE part: one resource, no per-sample test
+                    auto part_of = [&](int icz) {
+                        uint32_t q = 0u;
+                        for (uint32_t k = 1; k < L.nparts; ++k) q += icz >= zth + (int)((k - 1u) * L.zsplit) ? 1u : 0u;
+                        return q;
+                    };
+                    const float2_t ends = { (float)n, (float)min(n + U - 1, nsteps - 1) };     // (samples beyond the ray's end are never looked at)
+                    const float2_t ez2 = (ends * Rtz + Rsz) * ssz;
+                    const uint32_t pa = part_of((int)ez2.x), pb = part_of((int)ez2.y);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pa, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(live)));
+                    if (__builtin_amdgcn_ballot_w64(live && (pa != p0 || pb != p0)) == 0) {
+                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0);
+                        const uint32_t sub = p0 * L.part_bytes;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rp, live ? off[u] - sub : 0xFFFFFFFFu);
+                    } else {
                     float2_t it2 = { (float)n, (float)n + 1.0f };
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
@@ -1276,6 +1293,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             }
                             s[u + h] = a;
                         }
+                    }
                     }
                 } else
                 if (live) {
