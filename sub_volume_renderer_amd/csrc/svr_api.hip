@@ -843,6 +843,14 @@ static bool span_addressable(const svr_ctx* c) {
     return true;
 }
 
+// Rings of 4 GiB or more in total take the BIG build of the march (one buffer resource per LOD, several for a ring of
+// 4 GiB or more).  -DSVR_EXPERIMENTS builds can force that path onto small rings (SVR_FORCE_BIG=1) and cut them into
+// parts of SVR_FORCE_ZSPLIT planes, so that the fuzzer reaches the multi-resource addressing with part boundaries everywhere.
+static bool rings_need_big(const svr_ctx* c) {
+    static const bool force_big = svr_exp_env_int("SVR_FORCE_BIG", 0) != 0;
+    return c->density_all_bytes >= ((size_t)1 << 32) || force_big;
+}
+
 // Behind a draw that may have read a cost-sorted table: mark the stream's slot (see CostOrder::drawn).
 static int cost_order_drawn(svr_ctx* c, const MarchParams& P, hipStream_t stream) {
     for (auto& t : c->cost_orders)
@@ -903,7 +911,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     // the weighted-average mode rides the span march (another reducer over the same batches); rings the span march
     // cannot address, and variant 1, take march_wavg, which is laid out like the simple kernel
     const bool wavg_simple = m.render_mode == SVR_MODE_WEIGHTED_AVERAGE &&
-                             ((c->variant & 3) == 1 || !span_addressable(c) || c->density_all_bytes >= ((size_t)1 << 32));
+                             ((c->variant & 3) == 1 || !span_addressable(c) || rings_need_big(c));
     if ((c->variant & 3) == 1 || wavg_simple) lw = 3;         // the simple kernels are 8x8 only
     P.tile_log2w = lw;
     P.brick = (c->variant & 256) ? 0 : ((c->variant & 512) ? 2 : 1);     // never / always / auto (per wave)
@@ -1031,7 +1039,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     }
     P.density_all = c->density_all;
     P.span_ok = span_addressable(c) ? 1 : 0;
-    P.per_lod_rsrc = c->density_all_bytes >= ((size_t)1 << 32) ? 1 : 0;
+    P.per_lod_rsrc = rings_need_big(c) ? 1 : 0;
     P.density_all_bytes = P.per_lod_rsrc ? 0u : (uint32_t)c->density_all_bytes;
     for (int l = 0; l < c->num_lods; ++l) {
         LodParams& Q = P.lod[l];
@@ -1040,7 +1048,15 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             const uint64_t des64 = svr_dtype_size(c->density_storage);
             const uint64_t plane = (uint64_t)Q.ring[0] * (uint64_t)Q.ring[1] * des64, bytes = (uint64_t)c->lod[l].voxels * des64;
             Q.rbase = c->lod[l].density; Q.base_bytes = 0u;
-            if (bytes + 64 < ((uint64_t)1 << 32)) {
+            static const int force_zsplit = svr_exp_env_int("SVR_FORCE_ZSPLIT", 0);      // (see rings_need_big)
+            if (force_zsplit > 0 && Q.ring[2] > 1u) {
+                Q.zsplit = std::max<uint32_t>((uint32_t)force_zsplit, (Q.ring[2] + 7u) / 8u);
+                Q.zsplit = std::min<uint32_t>(Q.zsplit, Q.ring[2]);
+                Q.nparts = (Q.ring[2] + Q.zsplit - 1u) / Q.zsplit;
+                Q.part_bytes = Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
+                Q.rbytes_last = (uint32_t)(bytes - (uint64_t)(Q.nparts - 1) * Q.part_bytes + 64);
+                if (Q.nparts == 1u) { Q.rbytes = Q.rbytes_last; Q.part_bytes = 0u; }
+            } else if (bytes + 64 < ((uint64_t)1 << 32)) {
                 Q.rbytes = Q.rbytes_last = (uint32_t)(bytes + 64);
             } else {                                         // parts of whole ring z planes (span_addressable checked the count)
                 Q.zsplit = (uint32_t)std::min<uint64_t>((uint64_t)Q.ring[2], (((uint64_t)1 << 32) - 128) / plane);
