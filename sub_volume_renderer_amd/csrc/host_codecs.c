@@ -83,6 +83,8 @@ static int pool_start_gen[POOL_MAX + 1];     /* the generation a worker was crea
  * starts on its waker's CPU and the scheduler does not spread the team before the job is over (measured: 8 threads, one
  * CPU's worth of progress on 60 us items). */
 static void pool_pin(int id) {
+    const char* e = getenv("SVR_ZARR_PIN");              /* A/B: 0 leaves the workers to the scheduler */
+    if (e && e[0] == '0') return;
     cpu_set_t allowed, one;
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
     const int count = CPU_COUNT(&allowed);
