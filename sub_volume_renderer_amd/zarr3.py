@@ -247,9 +247,10 @@ def _native_tail(chain: "_Chain"):
 
 
 def _threads(reading: bool = True) -> int:
-    """Worker threads of the native codec: the CPUs this process may use (affinity mask capped by the cgroup quota) —
-    HALF of them for reads, which run on a streaming worker beside a render thread (a decoder team that takes the whole
-    CPU quota gets the process throttled, and a throttled render thread stalls frames); ``SVR_ZARR_THREADS`` overrides."""
+    """Worker threads of the native codec: the CPUs this process may use (affinity mask capped by the cgroup quota);
+    ``SVR_ZARR_THREADS`` overrides.  The pool's workers sleep between requests, so a full-width team beside a render
+    thread does not get the process throttled the way a spinning OpenMP team did (config 4 on the one-GPU box, 8 / 12 /
+    16 threads: 4.5 / 4.9 / 5.4 GB/s delivered, frame-time tail unchanged: ``profiles/r03/host_thread_pinning.txt``)."""
     if os.environ.get("SVR_ZARR_THREADS"):
         return max(1, int(os.environ["SVR_ZARR_THREADS"]))
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -260,7 +261,7 @@ def _threads(reading: bool = True) -> int:
             n = min(n, max(1, -(-int(q) // int(per))))
     except (OSError, ValueError):
         pass
-    return max(1, min(32, n // 2 if reading else n))
+    return max(1, min(32, n))
 
 
 class ZarrV3Array:
