@@ -85,3 +85,38 @@ def test_pool_kernels_stream_at_a_sane_fraction_of_hbm_rate(capsys):
             print(f"\npool2x {mode} {dtype}: {ms:.3f} ms, {gbs:.0f} GB/s ({gbs / 8000:.2f} of HBM peak)")
         assert gbs > 800.0, (mode, gbs)
         del t
+
+
+@pytest.mark.gpu
+def test_write_multiscale_store_equals_the_reference_pooling_rules(tmp_path):
+    """The reference's offline builders in one call: level 0 streamed through the GPU pool kernels slab by slab, every
+    level written as a sharded zstd zarr v3 array; what comes back from the stores is the closed-form volume's own
+    LODs (mean pooling for density, max pooling for labels), and a SubVolume fed the stores renders like one fed numpy."""
+    from sub_volume_renderer_amd import testing, zarr3
+    from sub_volume_renderer_amd.pyramid import write_multiscale_store
+
+    n = 256
+    d0, l0 = synth.volume(n, 0)
+    raw = write_multiscale_store(str(tmp_path / "raw.zarr"), d0, 3, "mean")
+    lab = write_multiscale_store(str(tmp_path / "labels.zarr"), l0, 3, "max")
+    assert sorted(zarr3.open_group(str(tmp_path / "raw.zarr")).keys()) == ["scale0", "scale1", "scale2"]
+    for k in range(3):
+        dk, lk = synth.volume(n, k)
+        assert raw[k].shape == dk.shape and raw[k].chunks == (16, 16, 16) and raw[k].shards == (64, 64, 64)
+        np.testing.assert_array_equal(raw[k][:, :, :], dk)
+        np.testing.assert_array_equal(lab[k][:, :, :], lk)
+    with pytest.raises(ValueError, match="divisible"):
+        write_multiscale_store(str(tmp_path / "bad.zarr"), d0[:250], 3, "mean")
+    # the stores as backing data == the numpy arrays as backing data
+    import torch
+
+    spec_np = testing.synthetic_spec(n, 200, 120, threshold=0.45, pairs=[synth.volume(n, k) for k in range(3)])
+    spec_z = testing.synthetic_spec(n, 200, 120, threshold=0.45, pairs=list(zip(raw, lab)))
+    a, b = testing.build(spec_np), testing.build(spec_z)
+    ra = a.volume.render(a.camera, 200, 120)
+    rb = b.volume.render(b.camera, 200, 120)
+    torch.cuda.synchronize()
+    assert a.volume._rings.density_storage == b.volume._rings.density_storage == "uint8"
+    assert torch.equal(ra.flags, rb.flags), int((ra.flags != rb.flags).sum())
+    assert torch.equal(ra.label, rb.label) and torch.equal(ra.rgba, rb.rgba)
+    assert int((ra.flags == 2).sum()) > 100, int((ra.flags == 2).sum())
