@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../../include/svr_host_codecs.h"
+
 static uint32_t T[8][256];
 static int ready;
 

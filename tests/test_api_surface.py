@@ -215,3 +215,31 @@ def test_segmentations_are_optional_but_all_or_none():
     assert SubVolume(SubVolumeMaterial(0.5), [(d0, d0), (d1, d1)], (2, 2, 2), (4, 4, 4))._rings.labels is True
     with pytest.raises(ValueError):
         SubVolume(SubVolumeMaterial(0.5), [(d0, d0), (d1, None)], (2, 2, 2), (4, 4, 4))
+
+
+def test_host_codec_header_symbols_are_exported_and_the_header_is_plain_c(tmp_path):
+    """include/svr_host_codecs.h (the native half of the chunk-store reader): every function it declares is exported by
+    libsvr_hostcodec.so, which loads without a GPU and without torch; the header compiles as strict C and as C++."""
+    import shutil
+    import subprocess
+
+    import __graft_entry__ as g
+
+    header = open(os.path.join(ROOT, "include", "svr_host_codecs.h")).read()
+    names = re.findall(r"^\s*(?:uint32_t|int|size_t)\s+(svr_\w+)\s*\(", header, flags=re.M)
+    assert sorted(names) == ["svr_crc32c", "svr_zarr_decode_chunks", "svr_zarr_encode_bound", "svr_zarr_encode_chunks",
+                             "svr_zarr_read_groups"]
+    lib = ctypes.CDLL(g.build_host_codecs())
+    for s in names:
+        assert hasattr(lib, s), f"{s} not exported by libsvr_hostcodec.so"
+    lib.svr_crc32c.restype = ctypes.c_uint32
+    lib.svr_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32]
+    assert lib.svr_crc32c(b"123456789", 9, 0) == 0xE3069283
+    gcc, gxx = shutil.which("gcc"), shutil.which("g++")
+    if gcc is None or gxx is None:
+        pytest.skip("no C / C++ compiler on this machine")
+    unit = tmp_path / "unit.c"
+    unit.write_text('#include "svr_host_codecs.h"\nint main(void) { return svr_crc32c("", 0, 0) != 0; }\n')
+    strict = ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only"]
+    subprocess.run([gcc, "-std=c99", *strict, str(unit)], check=True)
+    subprocess.run([gxx, "-std=c++17", *strict, "-x", "c++", str(unit)], check=True)
