@@ -415,10 +415,25 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
     return j;
 }
 
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+// EXPERIMENT (tools/exp_tiled_rings.py): density rings laid out in 128-byte micro-blocks that are compact in 3-D
+// (8 x 4 x 4 voxels of 1 byte, 4 x 4 x 4 of 2, 4 x 4 x 2 of 4) instead of 128-byte pieces of one x row; blocks in
+// [bz][by][bx] order.  The slot (wx, wy, wz) of a ring of Ry x Rx slots per plane -> byte offset from the ring's base.
+// SVR_EXP_TILED is the mask of LODs whose ring is laid out that way (bit l); the others stay linear and may stage bricks.
+constexpr uint32_t kTiledLods = (uint32_t)(SVR_EXP_TILED);
+template <int ESH>
+__device__ __forceinline__ uint32_t tiled_offset(uint32_t Rx, uint32_t Ry, uint32_t wx, uint32_t wy, uint32_t wz) {
+    constexpr uint32_t XB = ESH == 0 ? 3u : 2u, YB = 2u, ZB = ESH == 2 ? 1u : 2u;
+    const uint32_t blk = __umul24(__umul24(wz >> ZB, Ry >> YB) + (wy >> YB), Rx >> XB) + (wx >> XB);
+    const uint32_t inb = ((((wz & ((1u << ZB) - 1u)) << YB) | (wy & 3u)) << XB) | (wx & ((1u << XB) - 1u));
+    return (blk << 7) + (inb << ESH);
+}
+#endif
+
 // Byte offset (inside MarchParams::density_all) of the texel under data coord d for a
 // voxel KNOWN to lie in LOD L's ROI; general form with the explicit ring wrap.
 template <int ESH, typename LodT>
-__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, float dy, float dz) {
+__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, float dy, float dz, bool tiled = false) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -426,13 +441,16 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, 
     wx = min(wx, wx - L.ring[0]);
     wy = min(wy, wy - L.ring[1]);
     wz = min(wz, wz - L.ring[2]);
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+    if (tiled) return tiled_offset<ESH>(L.ring[0], L.ring[1], wx, wy, wz) + L.base_bytes;
+#endif
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
 // The same for a ring that is reached through several buffer resources (4 GiB or more: parts of LodParams::zsplit
 // planes): the offset is relative to the part that holds the slot's z plane, `part` says which
 template <int ESH, typename LodT>
-__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, uint32_t& part) {
+__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, uint32_t& part, bool tiled = false) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -443,6 +461,9 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, floa
     part = 0u;
     for (uint32_t k = 1; k < L.nparts; ++k) part += wz >= k * L.zsplit ? 1u : 0u;         // nparts <= 8, wave-uniform
     wz -= part * L.zsplit;
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+    if (tiled) return tiled_offset<ESH>(L.ring[0], L.ring[1], wx, wy, wz) + L.base_bytes;     // (zsplit: a whole number of blocks)
+#endif
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
@@ -838,6 +859,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // span state: iterations [.., E) use LOD `code` (NL = none) with address constant Kc
     int code = NL, E = 0;
     uint32_t Kc = 0xFFFFFFFFu;
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+    uint32_t Kx = 0u, Ky = 0u, Kz = 0u;              // tiled rings: the slot is not linear in the voxel index, the wrap constants stay apart
+#endif
     int zth = 0;                 // BIG builds: first voxel index ic_z whose ring plane lies in the LOD's upper resource
 
     // Wave-static routing of fast runs (u8 rings).  LDS bricks pay when the samples a wave fetches
@@ -893,6 +917,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
                         Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << ESH) + L.base_bytes;  // mod 2^32
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+                        Kx = kx; Ky = ky; Kz = kz;
+#endif
                         if constexpr (BIG) zth = (int)L.zsplit - (int)kz;                 // slot plane ic_z + kz >= k * zsplit <=> ic_z >= zth + (k - 1) * zsplit
                         if (ev[l].cx > n) E = min(E, ev[l].cx);
                         if (ev[l].cy > n) E = min(E, ev[l].cy);
@@ -937,7 +964,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     for (int l = 0; l < NL; ++l) {
                         const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
                         if (__builtin_amdgcn_ballot_w64(sel) != 0) {
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+                            const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz, ((kTiledLods >> l) & 1u) != 0u);
+#else
                             const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz);
+#endif
                             off[u] = sel ? ofs : off[u];
                         }
                         done = done || sel;
@@ -962,7 +993,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         if (__builtin_amdgcn_ballot_w64(sel) != 0) {
                             const LodK Lg = load_lod(Pg, l);
                             uint32_t part;
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+                            const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, part, ((kTiledLods >> l) & 1u) != 0u);
+#else
                             const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, part);
+#endif
                             // (a ring of 4 GiB or more: one load per part that some lane's texel lies in)
                             for (unsigned long long todo = __builtin_amdgcn_ballot_w64(sel); todo != 0ull;) {
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
@@ -1246,6 +1281,13 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 for (int u = 0; u < U; u += 2) {
                     const Idx2 v = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                     iter += 2.0f;
+#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
+                    if ((kTiledLods >> first) & 1u) {         // (wave-uniform; the caller keeps bricks off these LODs: variant bits 24-31)
+                        off[u] = tiled_offset<ESH>(L.ring[0], L.ring[1], v.x0 + Kx, v.y0 + Ky, v.z0 + Kz) + L.base_bytes;
+                        off[u + 1] = tiled_offset<ESH>(L.ring[0], L.ring[1], v.x1 + Kx, v.y1 + Ky, v.z1 + Kz) + L.base_bytes;
+                        continue;
+                    }
+#endif
                     off[u] = mad24(mad24(v.z0, L.ring[1], v.y0), L.rx4, shl_add_c<ESH>(v.x0, Kc));
                     off[u + 1] = mad24(mad24(v.z1, L.ring[1], v.y1), L.rx4, shl_add_c<ESH>(v.x1, Kc));
                 }
