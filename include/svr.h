@@ -35,7 +35,7 @@ extern "C" {
 
 #define SVR_MAX_LODS 8
 #define SVR_MAX_CLIP_PLANES 8
-#define SVR_ABI_VERSION 6
+#define SVR_ABI_VERSION 7
 
 typedef enum svr_status {
     SVR_OK = 0,
@@ -67,6 +67,15 @@ typedef struct svr_lod_desc {
                                       ring is allocated (4 of the 5 bytes per slot), uploads must pass labels = NULL,
                                       every hit gets label 0 (-> colors[0], like unlabelled voxels: FUTURE.md:170-176).
                                       All LODs of a context alike. */
+    int32_t blocked_twin;          /* 1: keep a SECOND copy of this LOD's density ring, laid out in 128-byte micro-blocks that
+                                      are compact in 3-D (8 x 4 x 4 one-byte voxels, 4 x 4 x 4 two-byte, 4 x 4 x 2 four-byte;
+                                      blocks in [bz][by][bx] order) — the locality a texture unit's tiled 3-D layout gives the
+                                      reference's textureLoad (sample_vol.wgsl:24).  Every upload writes both copies; the march
+                                      reads the same texels from whichever copy suits a wave's view: waves whose gathers would
+                                      touch many 128-byte ROWS per load (the per-wave probe that otherwise stages LDS bricks)
+                                      gather from the micro-blocks instead.  Costs one more density element per voxel of HBM and
+                                      of upload traffic; results are identical.  ring_dims must be multiples of (8, 4, 4), else
+                                      SVR_ERR_INVALID.  Meant for the finest LOD (the Python mirror's "auto" sets it there). */
 } svr_lod_desc;
 
 /* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.
@@ -250,7 +259,8 @@ int  svr_render(svr_ctx* ctx, const svr_camera* cam, const svr_frame* frame,
  *            than their plain length (default: twice), +8 = no empty-space skipping in LMIP mode (default: waves skip
  *            stretches whose macro-cell maxima stay below the threshold while no lane tracks a maximum)
  * bits 4-7  1 + log2(wave tile width): wave tile = 2^k x 64/2^k pixels (0 = default 8x8)
- * bit  8    never stage LDS bricks; bit 9: always stage them (default: per-wave probe; u8 rings only)
+ * bit  8    never stage LDS bricks nor gather from a micro-block twin (linear gathers only); bit 9: always
+ *            (default: per-wave probe)
  * bit  10   keep row-major lane order (default: lanes follow the projected x axis)
  * bits 11-12 reserved: SVR_ERR_INVALID.  (Builds made with -DSVR_EXPERIMENTS — tools/ab_build.py, never the shipped
  *            library — use them for timing experiments that render WRONG pixels, and read the SVR_* environment
@@ -322,6 +332,8 @@ int  svr_sync(svr_ctx* ctx);                 /* both streams idle */
 int  svr_sync_uploads(svr_ctx* ctx);         /* upload stream idle */
 /* raw device pointers of one LOD's ring textures (for diagnostics / RCCL) */
 int  svr_lod_device_ptrs(svr_ctx* ctx, int lod, void** density, void** labels);
+/* the micro-block copy of the LOD's density ring (svr_lod_desc::blocked_twin), or NULL: tests compare it with the ring */
+int  svr_lod_twin_ptr(svr_ctx* ctx, int lod, void** twin);
 
 /* diagnostics: batch census accumulated by instrumented renders (outputs.steps != NULL):
  * [0] general batches, [1] direct fast batches, [2] brick batches, [3] brick slabs, [4] runs,

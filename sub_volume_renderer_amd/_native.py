@@ -36,7 +36,8 @@ def dtype_code(dt) -> int:
 
 
 class LodDesc(C.Structure):
-    _fields_ = [("ring_dims", C.c_int32 * 3), ("density_storage", C.c_int32), ("no_labels", C.c_int32)]
+    _fields_ = [("ring_dims", C.c_int32 * 3), ("density_storage", C.c_int32), ("no_labels", C.c_int32),
+                ("blocked_twin", C.c_int32)]
 
 
 SVR_U8, SVR_U16, SVR_F32 = 0, 1, 8
@@ -151,6 +152,7 @@ SIGNATURES = {
     "svr_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
     "svr_debug_timers": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "svr_lod_device_ptrs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "svr_lod_twin_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "svr_time_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(Frame),
                                   C.POINTER(Outputs), C.c_int, C.POINTER(C.c_float)]),
 }

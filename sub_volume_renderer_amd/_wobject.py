@@ -86,6 +86,7 @@ class SubVolume(_HasWorld):
         *,
         device: int | None = None,
         ring_storage: str = "native",
+        blocked_twin="auto",
     ):
         super().__init__()
         pairs = list(data_segmentation_pairs)
@@ -130,6 +131,9 @@ class SubVolume(_HasWorld):
             # memory traffic); "float32": always the reference's r32float layout
             density_storage=native_density_storage([d for d, _ in data_segmentation_pairs], ring_storage),
             labels=not all(unlabelled),
+            # "auto": the finest scale's density ring is kept in two layouts — rows, and 128-byte micro-blocks that are
+            # compact in 3-D; each wave of the march gathers from the one that suits its view (include/svr.h)
+            blocked_twin=blocked_twin,
         )
         self.wrapping_buffers: list[WrappingBuffer] = []
         for i, (scale_data, scale_segmentations) in enumerate(data_segmentation_pairs):

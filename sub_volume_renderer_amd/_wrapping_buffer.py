@@ -33,7 +33,8 @@ from ._geometry import Coordinate, Roi
 class DeviceRings:
     """The ``svr_ctx`` that owns the ring textures of all LODs of one volume."""
 
-    def __init__(self, ring_shapes, device: int | None = None, density_storage: str = "float32", labels: bool = True):
+    def __init__(self, ring_shapes, device: int | None = None, density_storage: str = "float32", labels: bool = True,
+                 blocked_twin="auto"):
         # ring_shapes: numpy-order voxel extents, one per LOD
         self.ring_shapes = [tuple(int(v) for v in s) for s in ring_shapes]
         self.device = device
@@ -43,6 +44,10 @@ class DeviceRings:
             raise ValueError("density_storage must be 'float32', 'uint8' or 'uint16'")
         self.density_storage = density_storage
         self.labels = bool(labels)            # False: a volume without segmentation, no label rings at all
+        # Which LODs keep a second copy of their density ring in 128-byte micro-blocks (svr_lod_desc::blocked_twin):
+        # "auto" = the finest one when its extents allow (multiples of (8, 4, 4) in x, y, z), True = every LOD whose
+        # extents allow, False = none, or one bool per LOD (an extent that does not allow it is a ValueError then).
+        self.blocked_twin = blocked_twin_lods(self.ring_shapes, blocked_twin)
         self._handle = None
         self._closed = False
 
@@ -57,6 +62,8 @@ class DeviceRings:
                 d.ring_dims[:] = s[::-1]
                 d.density_storage = {"uint8": N.SVR_U8, "uint16": N.SVR_U16}.get(self.density_storage, N.SVR_F32)
                 d.no_labels = 0 if self.labels else 1
+            for d, twin in zip(descs, self.blocked_twin):
+                d.blocked_twin = 1 if twin else 0
             device = self.device
             if device is None:
                 import torch
@@ -124,6 +131,24 @@ class _UniformView:
 
 def _is_device_tensor(a) -> bool:
     return type(a).__module__.split(".")[0] == "torch" and bool(getattr(a, "is_cuda", False))
+
+
+def blocked_twin_lods(ring_shapes, blocked_twin="auto") -> list[bool]:
+    """Per LOD: does its density ring get a micro-block copy?  (ring_shapes in numpy order)"""
+    fits = [s[2] % 8 == 0 and s[1] % 4 == 0 and s[0] % 4 == 0 for s in ring_shapes]
+    if isinstance(blocked_twin, str):
+        if blocked_twin != "auto":
+            raise ValueError("blocked_twin must be 'auto', a bool or one bool per LOD")
+        return [i == 0 and ok for i, ok in enumerate(fits)]
+    if isinstance(blocked_twin, (bool, np.bool_)):
+        return [bool(blocked_twin) and ok for ok in fits]
+    wanted = [bool(v) for v in blocked_twin]
+    if len(wanted) != len(fits):
+        raise ValueError(f"blocked_twin list length ({len(wanted)}) must match number of scales ({len(fits)})")
+    for i, (w, ok) in enumerate(zip(wanted, fits)):
+        if w and not ok:
+            raise ValueError(f"blocked_twin[{i}]: ring extents {tuple(ring_shapes[i])} are not multiples of (4, 4, 8)")
+    return wanted
 
 
 def native_density_storage(arrays, ring_storage: str = "native") -> str:

@@ -415,25 +415,10 @@ __device__ __forceinline__ int first_cross(int n, float start, float step, float
     return j;
 }
 
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-// EXPERIMENT (tools/exp_tiled_rings.py): density rings laid out in 128-byte micro-blocks that are compact in 3-D
-// (8 x 4 x 4 voxels of 1 byte, 4 x 4 x 4 of 2, 4 x 4 x 2 of 4) instead of 128-byte pieces of one x row; blocks in
-// [bz][by][bx] order.  The slot (wx, wy, wz) of a ring of Ry x Rx slots per plane -> byte offset from the ring's base.
-// SVR_EXP_TILED is the mask of LODs whose ring is laid out that way (bit l); the others stay linear and may stage bricks.
-constexpr uint32_t kTiledLods = (uint32_t)(SVR_EXP_TILED);
-template <int ESH>
-__device__ __forceinline__ uint32_t tiled_offset(uint32_t Rx, uint32_t Ry, uint32_t wx, uint32_t wy, uint32_t wz) {
-    constexpr uint32_t XB = ESH == 0 ? 3u : 2u, YB = 2u, ZB = ESH == 2 ? 1u : 2u;
-    const uint32_t blk = __umul24(__umul24(wz >> ZB, Ry >> YB) + (wy >> YB), Rx >> XB) + (wx >> XB);
-    const uint32_t inb = ((((wz & ((1u << ZB) - 1u)) << YB) | (wy & 3u)) << XB) | (wx & ((1u << XB) - 1u));
-    return (blk << 7) + (inb << ESH);
-}
-#endif
-
 // Byte offset (inside MarchParams::density_all) of the texel under data coord d for a
 // voxel KNOWN to lie in LOD L's ROI; general form with the explicit ring wrap.
 template <int ESH, typename LodT>
-__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, float dy, float dz, bool tiled = false) {
+__device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, float dy, float dz) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -441,16 +426,13 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped(const LodT& L, float dx, 
     wx = min(wx, wx - L.ring[0]);
     wy = min(wy, wy - L.ring[1]);
     wz = min(wz, wz - L.ring[2]);
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-    if (tiled) return tiled_offset<ESH>(L.ring[0], L.ring[1], wx, wy, wz) + L.base_bytes;
-#endif
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
 // The same for a ring that is reached through several buffer resources (4 GiB or more: parts of LodParams::zsplit
 // planes): the offset is relative to the part that holds the slot's z plane, `part` says which
 template <int ESH, typename LodT>
-__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, uint32_t& part, bool tiled = false) {
+__device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, float dx, float dy, float dz, uint32_t& part) {
     float sx = dx * L.scale[0], sy = dy * L.scale[1], sz = dz * L.scale[2];
     uint32_t wx = (uint32_t)((int)sx + L.addw[0]);
     uint32_t wy = (uint32_t)((int)sy + L.addw[1]);
@@ -461,17 +443,32 @@ __device__ __forceinline__ uint32_t lod_offset_wrapped_split(const LodT& L, floa
     part = 0u;
     for (uint32_t k = 1; k < L.nparts; ++k) part += wz >= k * L.zsplit ? 1u : 0u;         // nparts <= 8, wave-uniform
     wz -= part * L.zsplit;
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-    if (tiled) return tiled_offset<ESH>(L.ring[0], L.ring[1], wx, wy, wz) + L.base_bytes;     // (zsplit: a whole number of blocks)
-#endif
     return __umul24(__umul24(wz, L.ring[1]) + wy, L.rx4) + L.base_bytes + (wx << ESH);
 }
 
-// the buffer resource of part p (wave-uniform) of such a ring
+// the buffer resource of part p (wave-uniform) of such a ring — or of its micro-block copy, which is cut the same way
 template <typename LodT>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint32_t p) {
-    const char* base = static_cast<const char*>(L.rbase) + (size_t)p * (size_t)L.part_bytes;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint32_t p, const void* ring_base) {
+    const char* base = static_cast<const char*>(ring_base) + (size_t)p * (size_t)L.part_bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(p + 1u == L.nparts ? L.rbytes_last : L.rbytes), 0x00020000);
+}
+template <typename LodT>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint32_t p) { return part_rsrc(L, p, L.rbase); }
+
+// Micro-block copy of a ring (svr_lod_desc::blocked_twin; host: svr_blocked_index): 128-byte blocks of
+// 2^XB x 2^YB x 2^ZB slots in [bz][by][bx] order, the slots of a block in [z][y][x] order.
+template <int ESH> struct TwinBlock { static constexpr int XB = ESH == 0 ? 3 : 2, YB = 2, ZB = ESH == 2 ? 1 : 2; };
+// Byte offset of the texel of voxel (x, y, z) in that copy, for a lane whose ring slot is voxel + (kx, ky, kz) with
+// constants that are multiples of the ring extents — and therefore of the block extents: the block coordinates of the
+// slot are those of the voxel plus constants, the position inside the block is the voxel's own low bits.  Kb = the
+// constants' part of the block number (+ the copy's offset in the resource, in blocks); all mod 2^32.
+template <int ESH>
+__device__ __forceinline__ uint32_t twin_offset(uint32_t x, uint32_t y, uint32_t z, int nbx, int nby, uint32_t Kb) {
+    typedef TwinBlock<ESH> B;
+    const int bx = (int)x >> B::XB, by = (int)y >> B::YB, bz = (int)z >> B::ZB;        // (arithmetic: a voxel index may be negative)
+    const int blk = __mul24(__mul24(bz, nby) + by, nbx) + bx;
+    const uint32_t inb = ((((z & ((1u << B::ZB) - 1u)) << B::YB) | (y & 3u)) << B::XB) | (x & ((1u << B::XB) - 1u));
+    return (((uint32_t)blk + Kb) << 7) | (inb << ESH);
 }
 
 // Raw texel as fetched: f32 rings (ESH = 2) hold the sample itself, u8 rings (ESH = 0) the byte,
@@ -634,6 +631,8 @@ struct LodK {
     const void* rbase;
     uint32_t rbytes;
     uint32_t nparts, zsplit, part_bytes, rbytes_last;      // rings of 4 GiB or more: parts of zsplit planes (LodParams)
+    uint32_t twin, twin_base_bytes;                        // micro-block copy of the ring (LodParams::twin)
+    const void* twin_rbase;
 };
 __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     LodK k;
@@ -644,6 +643,7 @@ __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
     k.rbase = p->lod[l].rbase; k.rbytes = p->lod[l].rbytes;
     k.nparts = p->lod[l].nparts; k.zsplit = p->lod[l].zsplit; k.part_bytes = p->lod[l].part_bytes; k.rbytes_last = p->lod[l].rbytes_last;
+    k.twin = p->lod[l].twin; k.twin_base_bytes = p->lod[l].twin_base_bytes; k.twin_rbase = p->lod[l].twin_rbase;
     return k;
 }
 
@@ -859,9 +859,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // span state: iterations [.., E) use LOD `code` (NL = none) with address constant Kc
     int code = NL, E = 0;
     uint32_t Kc = 0xFFFFFFFFu;
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-    uint32_t Kx = 0u, Ky = 0u, Kz = 0u;              // tiled rings: the slot is not linear in the voxel index, the wrap constants stay apart
-#endif
+    uint32_t Kb = 0u;            // the same for the micro-block copy of the span's LOD (twin_offset), kept by waves that gather from it
     int zth = 0;                 // BIG builds: first voxel index ic_z whose ring plane lies in the LOD's upper resource
 
     // Wave-static routing of fast runs (u8 rings).  LDS bricks pay when the samples a wave fetches
@@ -869,6 +867,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
     // of each quad).  Probe it: at one iteration, count how many lanes hit a line that no lower lane of
     // their quad hits; > kBrickQuadLines lookups per load -> stage bricks.  P.brick: 0 never, 1 probe, 2 always.
     int brick_mode = 0;                              // wave-uniform: 0 gathers only, k > 0 brick slabs of 2^(k-1) times the plain length
+    bool many_lines = false;                         // wave-uniform, for good: the probe's verdict (or "always").  On a LOD that
+                                                     // keeps a micro-block copy such a wave gathers from the copy instead of staging bricks
     if (P.brick) {
         const float pf = (float)min(max(nsteps - 1, 0), 256);
         const int qx = (int)((Rsx + pf * Rtx) * P.size[0]) >> (7 - ESH);   // 128 bytes per line
@@ -884,6 +884,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const int quads = __builtin_popcountll(__builtin_amdgcn_ballot_w64(frag && q == 0)) + 1;
         const bool use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;   // lookups per full wave-load
         brick_mode = use_brick ? 1 + P.slab_long : 0;
+        many_lines = use_brick;
     }
     const int wave_lds = wave * P.brick_bytes;
 
@@ -917,9 +918,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
                         Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << ESH) + L.base_bytes;  // mod 2^32
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-                        Kx = kx; Ky = ky; Kz = kz;
-#endif
+                        if (many_lines && L.twin) {
+                            typedef TwinBlock<ESH> B;
+                            Kb = (uint32_t)(((int)kz >> B::ZB) * (int)(L.ring[1] >> B::YB) + ((int)ky >> B::YB)) * (L.ring[0] >> B::XB) +
+                                 (uint32_t)((int)kx >> B::XB) + (L.twin_base_bytes >> 7);
+                        }
                         if constexpr (BIG) zth = (int)L.zsplit - (int)kz;                 // slot plane ic_z + kz >= k * zsplit <=> ic_z >= zth + (k - 1) * zsplit
                         if (ev[l].cx > n) E = min(E, ev[l].cx);
                         if (ev[l].cy > n) E = min(E, ev[l].cy);
@@ -964,11 +967,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     for (int l = 0; l < NL; ++l) {
                         const bool sel = !done && (n + u) >= ev[l].a && (n + u) < ev[l].b;
                         if (__builtin_amdgcn_ballot_w64(sel) != 0) {
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-                            const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz, ((kTiledLods >> l) & 1u) != 0u);
-#else
                             const uint32_t ofs = lod_offset_wrapped<ESH>(load_lod(Pg, l), dx, dy, dz);
-#endif
                             off[u] = sel ? ofs : off[u];
                         }
                         done = done || sel;
@@ -993,11 +992,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         if (__builtin_amdgcn_ballot_w64(sel) != 0) {
                             const LodK Lg = load_lod(Pg, l);
                             uint32_t part;
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-                            const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, part, ((kTiledLods >> l) & 1u) != 0u);
-#else
                             const uint32_t ofs = lod_offset_wrapped_split<ESH>(Lg, dx, dy, dz, part);
-#endif
                             // (a ring of 4 GiB or more: one load per part that some lane's texel lies in)
                             for (unsigned long long todo = __builtin_amdgcn_ballot_w64(sel); todo != 0ull;) {
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
@@ -1045,6 +1040,11 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             if constexpr (BIG) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.rbase), 0, (int)L.rbytes, 0x00020000);
             // (a ring of 4 GiB or more comes through nparts resources of L.zsplit planes each: part_rsrc)
             const bool ring_split = BIG && L.nparts > 1u;                // wave-uniform
+            // this wave's gathers on this LOD go to the micro-block copy of the ring (and it stages no bricks from the ring)
+            const bool use_twin = many_lines && L.twin != 0u;
+            const void* const gather_base = use_twin ? L.twin_rbase : L.rbase;
+            __amdgpu_buffer_rsrc_t rsrc_g = rsrc;
+            if constexpr (BIG) { if (use_twin) rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.rbytes, 0x00020000); }
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
             // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         // (a lane that is following a maximum is done within lmip_max_samples more samples: march just
                         // long enough for that, with plain gathers, and come back to skipping)
                         int cap = 4 * sb;
-                        if (brick_mode && L.slab > 0) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
+                        if (brick_mode && L.slab > 0 && !use_twin) cap = max(cap, (L.slab << (brick_mode - 1)) / U);
                         if (tracking_only && (P.skip_flags & 1) && !mip_like) cap = min(cap, 2);     // (MIP lanes follow their maximum to the ray's end)
                         if (run > cap) { held = run - cap; run = cap; }
                     }
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 // slab length (host: about 12 ring voxels of travel; 0 where this LOD cannot stage bricks)
                 // (a wave starts with slabs of twice that length: the staged bytes per sample fall with the slab
                 // length; at its first box that does not fit the LDS region it drops to the plain length)
-                while (brick_mode && L.slab > 0 && run >= (L.slab << (brick_mode - 1)) / U) {
+                while (brick_mode && L.slab > 0 && !use_twin && run >= (L.slab << (brick_mode - 1)) / U) {
                     const int slab = L.slab << (brick_mode - 1);
                     const bool live = alive && !finished && n < nsteps;
                     // first and last existing sample of the slab, both at once with the packed chain
@@ -1277,19 +1277,23 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 texel_t s[U];
                 uint32_t off[U];
                 float2_t iter = { (float)n, (float)n + 1.0f };
+                if (use_twin) {
+                    const int nbx = (int)(L.ring[0] >> TwinBlock<ESH>::XB), nby = (int)(L.ring[1] >> TwinBlock<ESH>::YB);
+#pragma unroll
+                    for (int u = 0; u < U; u += 2) {
+                        const Idx2 v = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
+                        iter += 2.0f;
+                        off[u] = twin_offset<ESH>(v.x0, v.y0, v.z0, nbx, nby, Kb);
+                        off[u + 1] = twin_offset<ESH>(v.x1, v.y1, v.z1, nbx, nby, Kb);
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < U; u += 2) {
                     const Idx2 v = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                     iter += 2.0f;
-#if defined(SVR_EXPERIMENTS) && defined(SVR_EXP_TILED)
-                    if ((kTiledLods >> first) & 1u) {         // (wave-uniform; the caller keeps bricks off these LODs: variant bits 24-31)
-                        off[u] = tiled_offset<ESH>(L.ring[0], L.ring[1], v.x0 + Kx, v.y0 + Ky, v.z0 + Kz) + L.base_bytes;
-                        off[u + 1] = tiled_offset<ESH>(L.ring[0], L.ring[1], v.x1 + Kx, v.y1 + Ky, v.z1 + Kz) + L.base_bytes;
-                        continue;
-                    }
-#endif
                     off[u] = mad24(mad24(v.z0, L.ring[1], v.y0), L.rx4, shl_add_c<ESH>(v.x0, Kc));
                     off[u + 1] = mad24(mad24(v.z1, L.ring[1], v.y1), L.rx4, shl_add_c<ESH>(v.x1, Kc));
+                }
                 }
                 // lanes that are not live fetch nothing; the LMIP update never looks at their samples
 #pragma unroll
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t pa = part_of((int)ez2.x), pb = part_of((int)ez2.y);
                     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pa, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(live)));
                     if (__builtin_amdgcn_ballot_w64(live && (pa != p0 || pb != p0)) == 0) {
-                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0);
+                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0, gather_base);
                         const uint32_t sub = p0 * L.part_bytes;
 #pragma unroll
                         for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rp, live ? off[u] - sub : 0xFFFFFFFFu);
@@ -1329,7 +1333,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             for (unsigned long long todo = __builtin_amdgcn_ballot_w64(live); todo != 0ull;) {
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
                                 const bool mine = live && part == p;
-                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p), mine ? rel : 0xFFFFFFFFu);
+                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p, gather_base), mine ? rel : 0xFFFFFFFFu);
                                 a = mine ? t : a;
                                 todo &= ~__builtin_amdgcn_ballot_w64(mine);
                             }
@@ -1340,7 +1344,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 } else
                 if (live) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc, off[u]);
+                    for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc_g, off[u]);
                 }
                 if (__builtin_amdgcn_ballot_w64(live && n + U > nsteps) != 0) lmip_batch(s, n, live, true);
                 else lmip_batch(s, n, live, false);

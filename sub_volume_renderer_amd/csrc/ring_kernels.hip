@@ -66,9 +66,23 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterArgs a) {
         if (a.src_density) {
             const char* p = static_cast<const char*>(a.src_density) +
                             (int64_t)x * a.dstride[0] + (int64_t)y * a.dstride[1] + (int64_t)z * a.dstride[2];
-            if (a.ring_storage == SVR_U8) static_cast<uint8_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint8_t*>(p);
-            else if (a.ring_storage == SVR_U16) static_cast<uint16_t*>(a.ring_density)[dst] = *reinterpret_cast<const uint16_t*>(p);
-            else static_cast<float*>(a.ring_density)[dst] = load_as_f32(p, a.density_dtype);
+            // (the micro-block copy of the ring, where the LOD keeps one, gets the same element)
+            const int esh = a.ring_storage == SVR_U8 ? 0 : (a.ring_storage == SVR_U16 ? 1 : 2);
+            const size_t tw = a.ring_twin ? svr_blocked_index(esh, (uint32_t)a.ring[0], (uint32_t)a.ring[1], x + (uint32_t)a.dst_off[0],
+                                                              y + (uint32_t)a.dst_off[1], z + (uint32_t)a.dst_off[2]) : 0;
+            if (a.ring_storage == SVR_U8) {
+                const uint8_t v = *reinterpret_cast<const uint8_t*>(p);
+                static_cast<uint8_t*>(a.ring_density)[dst] = v;
+                if (a.ring_twin) static_cast<uint8_t*>(a.ring_twin)[tw] = v;
+            } else if (a.ring_storage == SVR_U16) {
+                const uint16_t v = *reinterpret_cast<const uint16_t*>(p);
+                static_cast<uint16_t*>(a.ring_density)[dst] = v;
+                if (a.ring_twin) static_cast<uint16_t*>(a.ring_twin)[tw] = v;
+            } else {
+                const float v = load_as_f32(p, a.density_dtype);
+                static_cast<float*>(a.ring_density)[dst] = v;
+                if (a.ring_twin) static_cast<float*>(a.ring_twin)[tw] = v;
+            }
         }
         if (a.src_labels) {
             const char* p = static_cast<const char*>(a.src_labels) +
@@ -102,6 +116,27 @@ __global__ __launch_bounds__(256) void scatter_rows16(const ScatterArgs a, uint3
         for (int k = 0; k < DES; ++k) v[k] = __builtin_nontemporal_load(s + k);      // staged bytes are read once
 #pragma unroll
         for (int k = 0; k < DES; ++k) d[k] = v[k];
+        if (a.ring_twin) {
+            // the same 16 voxels into the micro-block copy: they start a block row (x is a multiple of 16) and are the x rows
+            // of 2 (1-byte voxels: 8 per row) or 4 (2- / 4-byte: 4 per row) consecutive blocks, 128 bytes apart.  The threads of
+            // the 4 y rows of a block run side by side in time, so its 32- / 64-byte z slices are written whole.
+            constexpr int ESH = DES == 1 ? 0 : (DES == 2 ? 1 : 2);
+            char* t = static_cast<char*>(a.ring_twin) +
+                      svr_blocked_index(ESH, (uint32_t)a.ring[0], (uint32_t)a.ring[1], g * 16u + (uint32_t)a.dst_off[0],
+                                        y + (uint32_t)a.dst_off[1], z + (uint32_t)a.dst_off[2]) * DES;
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            if constexpr (DES == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(t + k * 128) = v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < DES; ++k) {
+                    u32x2 lo = { v[k].x, v[k].y }, hi = { v[k].z, v[k].w };
+                    *reinterpret_cast<u32x2*>(t + (2 * k) * 128) = lo;
+                    *reinterpret_cast<u32x2*>(t + (2 * k + 1) * 128) = hi;
+                }
+            }
+        }
     }
     if (a.src_labels) {
         const u32x4* s = reinterpret_cast<const u32x4*>(static_cast<const char*>(a.src_labels) +

@@ -58,6 +58,10 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
                     "svr_create: density_storage must be SVR_F32, SVR_U8 or SVR_U16");
         SVR_REQUIRE(lods[l].density_storage == lods[0].density_storage,
                     "svr_create: all LODs must use the same density_storage");
+        SVR_REQUIRE(lods[l].blocked_twin == 0 || lods[l].blocked_twin == 1, "svr_create: blocked_twin must be 0 or 1");
+        SVR_REQUIRE(!lods[l].blocked_twin ||
+                    (lods[l].ring_dims[0] % 8 == 0 && lods[l].ring_dims[1] % 4 == 0 && lods[l].ring_dims[2] % 4 == 0),
+                    "svr_create: blocked_twin needs ring extents that are multiples of (8, 4, 4)");
         SVR_REQUIRE((lods[l].no_labels != 0) == (lods[0].no_labels != 0), "svr_create: all LODs must agree on no_labels");
     }
     DeviceGuard guard(device);
@@ -71,7 +75,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     for (auto& t : c->tickets) t = nullptr;
     c->uploads_marker = nullptr; c->marker_set = false; c->dbg_dev = nullptr;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
-    for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
+    for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].twin = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
     c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
     c->cells_raw_all = c->cells_dil_all = nullptr; c->cells_all_bytes = 0;
     c->density_storage = lods[0].density_storage;
@@ -98,22 +102,32 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         c->lod_base_bytes[l] = total;                         // voxel offset of this LOD
         total += (L.voxels + 255) & ~(size_t)255;
     }
+    // the micro-block copies (svr_lod_desc::blocked_twin) follow the rings in the density allocation: while all of it
+    // stays below 4 GiB, one buffer resource reaches the rings and their copies alike
+    const size_t ring_voxels = total;
+    size_t twin_base[SVR_MAX_LODS] = {0};
+    for (int l = 0; l < num_lods; ++l) {
+        if (!lods[l].blocked_twin) continue;
+        twin_base[l] = total;
+        total += (c->lod[l].voxels + 255) & ~(size_t)255;
+    }
     const size_t des = svr_dtype_size(c->density_storage);
     c->density_all_bytes = total * des + 64;                 // + slack: 16-byte brick loads may overrun a row end
     // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
     if (hipMalloc((void**)&c->density_all, c->density_all_bytes) != hipSuccess ||
-        (!c->no_labels && hipMalloc((void**)&c->labels_all, total * sizeof(uint32_t)) != hipSuccess)) {
+        (!c->no_labels && hipMalloc((void**)&c->labels_all, ring_voxels * sizeof(uint32_t)) != hipSuccess)) {
         svr_set_error("svr_create: out of device memory for ring textures");
         return fail(SVR_ERR_NOMEM);
     }
     if (hipMemsetAsync(c->density_all, 0, c->density_all_bytes, c->upload_stream) != hipSuccess ||
-        (!c->no_labels && hipMemsetAsync(c->labels_all, 0, total * sizeof(uint32_t), c->upload_stream) != hipSuccess)) {
+        (!c->no_labels && hipMemsetAsync(c->labels_all, 0, ring_voxels * sizeof(uint32_t), c->upload_stream) != hipSuccess)) {
         svr_set_error("svr_create: memset failed");
         return fail(SVR_ERR_HIP);
     }
     for (int l = 0; l < num_lods; ++l) {
         c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
         c->lod[l].labels = c->no_labels ? nullptr : c->labels_all + c->lod_base_bytes[l];
+        c->lod[l].twin = lods[l].blocked_twin ? static_cast<char*>(c->density_all) + twin_base[l] * des : nullptr;
     }
     {   // macro-cell maxima (empty-space skipping): one grid of cells per LOD whose extents are multiples of 8.
         // The finest level gets 8^3-slot cells, the coarser ones 4^3: their structures are half / a quarter the size
@@ -500,7 +514,7 @@ int svr_upload_region(svr_ctx* c, int lod, const int32_t dst_off[3], const int32
         a.dstride[0] = (int64_t)des; a.dstride[1] = (int64_t)des * shape[0]; a.dstride[2] = (int64_t)des * shape[0] * by;
         a.src_labels = labels ? static_cast<char*>(S.dev) + lofs : nullptr; a.labels_dtype = labels_dtype;
         a.lstride[0] = (int64_t)les; a.lstride[1] = (int64_t)les * shape[0]; a.lstride[2] = (int64_t)les * shape[0] * by;
-        a.ring_density = L.density; a.ring_labels = L.labels; a.ring_storage = c->density_storage;
+        a.ring_density = L.density; a.ring_labels = L.labels; a.ring_storage = c->density_storage; a.ring_twin = L.twin;
         for (int i = 0; i < 3; ++i) a.ring[i] = L.ring[i];
         a.dst_off[0] = dst_off[0]; a.dst_off[1] = dst_off[1] + y0; a.dst_off[2] = dst_off[2] + z0;
         a.shape[0] = shape[0]; a.shape[1] = by; a.shape[2] = bz;
@@ -539,7 +553,7 @@ int svr_upload_region_device(svr_ctx* c, int lod, const int32_t dst_off[3], cons
         a.lstride[i] = labels ? labels_strides[i] : 0;
         a.ring[i] = L.ring[i]; a.dst_off[i] = dst_off[i]; a.shape[i] = shape[i];
     }
-    a.ring_density = L.density; a.ring_labels = L.labels;
+    a.ring_density = L.density; a.ring_labels = L.labels; a.ring_twin = L.twin;
     SVR_HIP_TRY(scatter_into_ring(c, lod, a, density != nullptr));
     return SVR_OK;
 }
@@ -614,6 +628,7 @@ int svr_clear_lod(svr_ctx* c, int lod) {
     LodStorage& L = c->lod[lod];
     std::lock_guard<std::mutex> upload_lock(c->upload_mu);
     SVR_HIP_TRY(hipMemsetAsync(L.density, 0, L.voxels * svr_dtype_size(c->density_storage), c->upload_stream));
+    if (L.twin) SVR_HIP_TRY(hipMemsetAsync(L.twin, 0, L.voxels * svr_dtype_size(c->density_storage), c->upload_stream));
     if (L.labels) SVR_HIP_TRY(hipMemsetAsync(L.labels, 0, L.voxels * sizeof(uint32_t), c->upload_stream));
     if (L.cells_raw) {
         const size_t cb = (size_t)L.cdim[0] * L.cdim[1] * L.cdim[2] * svr_dtype_size(c->density_storage);
@@ -835,7 +850,8 @@ static bool span_addressable(const svr_ctx* c) {
     for (int l = 0; l < c->num_lods; ++l) {
         // (a ring of 4 GiB or more is reached through up to 8 resources of whole z planes, each below 4 GiB: 32 GiB)
         const uint64_t plane = (uint64_t)c->lod[l].ring[0] * (uint64_t)c->lod[l].ring[1] * des;
-        const uint64_t zsplit = plane ? std::min<uint64_t>((uint64_t)c->lod[l].ring[2], (((uint64_t)1 << 32) - 128) / plane) : 0;
+        uint64_t zsplit = plane ? std::min<uint64_t>((uint64_t)c->lod[l].ring[2], (((uint64_t)1 << 32) - 128) / plane) : 0;
+        if (zsplit < (uint64_t)c->lod[l].ring[2] && zsplit >= 4) zsplit &= ~(uint64_t)3;      // (parts of whole micro-blocks: fill_params)
         if (zsplit == 0 || ((uint64_t)c->lod[l].ring[2] + zsplit - 1) / zsplit > 8 ||
             (uint64_t)c->lod[l].ring[1] * (uint64_t)c->lod[l].ring[2] >= (1u << 24) ||
             (uint64_t)c->lod[l].ring[0] * des >= (1u << 24)) return false;
@@ -1044,6 +1060,12 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     for (int l = 0; l < c->num_lods; ++l) {
         LodParams& Q = P.lod[l];
         Q.nparts = 1u; Q.zsplit = Q.ring[2]; Q.part_bytes = 0u; Q.rbytes_last = 0u;
+        // the micro-block copy of the ring (svr_lod_desc::blocked_twin): inside the one resource, or a resource of its own
+        // that is cut into parts exactly like the ring's (parts of whole blocks: zsplit is a multiple of 4 planes)
+        Q.twin = c->lod[l].twin ? 1u : 0u;
+        Q.twin_base_bytes = (!P.per_lod_rsrc && c->lod[l].twin)
+                                ? (uint32_t)(static_cast<const char*>(c->lod[l].twin) - static_cast<const char*>(c->density_all)) : 0u;
+        Q.twin_rbase = P.per_lod_rsrc ? c->lod[l].twin : c->density_all;
         if (P.per_lod_rsrc) {
             const uint64_t des64 = svr_dtype_size(c->density_storage);
             const uint64_t plane = (uint64_t)Q.ring[0] * (uint64_t)Q.ring[1] * des64, bytes = (uint64_t)c->lod[l].voxels * des64;
@@ -1051,6 +1073,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
             static const int force_zsplit = svr_exp_env_int("SVR_FORCE_ZSPLIT", 0);      // (see rings_need_big)
             if (force_zsplit > 0 && Q.ring[2] > 1u) {
                 Q.zsplit = std::max<uint32_t>((uint32_t)force_zsplit, (Q.ring[2] + 7u) / 8u);
+                if (Q.twin) Q.zsplit = (Q.zsplit + 3u) & ~3u;
                 Q.zsplit = std::min<uint32_t>(Q.zsplit, Q.ring[2]);
                 Q.nparts = (Q.ring[2] + Q.zsplit - 1u) / Q.zsplit;
                 Q.part_bytes = Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
@@ -1060,6 +1083,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
                 Q.rbytes = Q.rbytes_last = (uint32_t)(bytes + 64);
             } else {                                         // parts of whole ring z planes (span_addressable checked the count)
                 Q.zsplit = (uint32_t)std::min<uint64_t>((uint64_t)Q.ring[2], (((uint64_t)1 << 32) - 128) / plane);
+                if (Q.zsplit < Q.ring[2] && Q.zsplit >= 4u) Q.zsplit &= ~3u;
                 Q.nparts = (uint32_t)(((uint64_t)Q.ring[2] + Q.zsplit - 1) / Q.zsplit);
                 Q.part_bytes = Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
                 Q.rbytes_last = (uint32_t)(bytes - (uint64_t)(Q.nparts - 1) * Q.part_bytes + 64);
@@ -1186,6 +1210,13 @@ int svr_debug_timers(svr_ctx* c, uint64_t out[16], int reset) {
     SVR_HIP_TRY(hipDeviceSynchronize());
     SVR_HIP_TRY(hipMemcpy(out, c->dbg_dev + 8, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (reset) SVR_HIP_TRY(hipMemset(c->dbg_dev + 8, 0, 16 * sizeof(uint64_t)));
+    return SVR_OK;
+}
+
+int svr_lod_twin_ptr(svr_ctx* c, int lod, void** twin) {
+    SVR_REQUIRE(c && twin, "svr_lod_twin_ptr: null argument");
+    SVR_REQUIRE(lod >= 0 && lod < c->num_lods, "svr_lod_twin_ptr: lod out of range");
+    *twin = c->lod[lod].twin;
     return SVR_OK;
 }
 

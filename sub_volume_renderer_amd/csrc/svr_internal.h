@@ -58,6 +58,11 @@ struct LodParams {
     uint32_t zsplit;
     uint32_t part_bytes;
     uint32_t rbytes_last;
+    // svr_lod_desc::blocked_twin: a second copy of this ring in 128-byte micro-blocks (svr_blocked_index).  It is split into
+    // parts exactly like the ring (same zsplit — a whole number of blocks —, part sizes and count)
+    uint32_t twin;             // 1: the copy exists
+    uint32_t twin_base_bytes;  // its byte offset inside the one-resource allocation (per_lod_rsrc = 0; a multiple of 256)
+    const void* twin_rbase;    // per_lod_rsrc = 1: its own resource starts here
     uint32_t cell_base;        // byte offset of the LOD's cell grid
     uint32_t cdim[3];          // cells per axis
     int32_t  cshift;           // log2 of the cell size (3 or 2)
@@ -130,6 +135,7 @@ struct LodStorage {
     int32_t  ring[3];          // x,y,z
     size_t   voxels;
     void*     density;
+    void*     twin;            // micro-block copy of `density` (svr_lod_desc::blocked_twin) or null
     uint32_t* labels;
     svr_lod_state state;
     // macro-cell maxima (8^3 or 4^3 slots per cell) for empty-space skipping; null when an extent is not a multiple of 8
@@ -240,6 +246,7 @@ struct ScatterArgs {
     const void* src_density; int density_dtype; int64_t dstride[3];   // bytes per x,y,z step
     const void* src_labels;  int labels_dtype;  int64_t lstride[3];
     void* ring_density; uint32_t* ring_labels;
+    void* ring_twin;               // micro-block copy of the density ring, written alongside (null: none)
     int32_t ring_storage;          // svr_dtype of the density ring: SVR_U8 / SVR_U16 / SVR_F32
     int32_t packed;                // the source is a staged block (x stride = element size, rows back to back)
     int32_t ring[3];
@@ -261,5 +268,15 @@ hipError_t svr_launch_untile(const void* gathered, void* frame_out, int frame_w,
 hipError_t svr_launch_pool2x(const void* src, void* dst, const int32_t dims[3], int dtype, int mode, hipStream_t stream);
 
 size_t svr_dtype_size(int dtype);
+
+// Element index of ring slot (x, y, z) in the micro-block copy of a ring of Rx x Ry slots per plane (esh = log2 of the
+// element size): 128-byte blocks of 8 x 4 x 4 (esh 0), 4 x 4 x 4 (1) or 4 x 4 x 2 (2) slots, blocks in [bz][by][bx] order,
+// the slots of a block in [z][y][x] order.  Ring extents are multiples of (8, 4, 4).
+__host__ __device__ inline size_t svr_blocked_index(int esh, uint32_t Rx, uint32_t Ry, uint32_t x, uint32_t y, uint32_t z) {
+    const uint32_t XB = esh == 0 ? 3u : 2u, YB = 2u, ZB = esh == 2 ? 1u : 2u;
+    const size_t blk = ((size_t)(z >> ZB) * (size_t)(Ry >> YB) + (size_t)(y >> YB)) * (size_t)(Rx >> XB) + (size_t)(x >> XB);
+    const uint32_t inb = ((((z & ((1u << ZB) - 1u)) << YB) | (y & 3u)) << XB) | (x & ((1u << XB) - 1u));
+    return (blk << (7 - esh)) + inb;
+}
 // integer rings hold the source values themselves: only sources of that very dtype may be uploaded
 inline bool storage_accepts(int storage, int src_dtype) { return storage == SVR_F32 || src_dtype == storage; }

@@ -35,6 +35,7 @@ class SceneSpec:
     region: FrameRegion | None = None
     colorspace: str = "srgb"
     ring_storage: str = "native"
+    blocked_twin: object = "auto"
 
     def camera(self) -> PerspectiveCamera:
         cam = PerspectiveCamera(self.fov, self.width / self.height, depth_range=self.depth_range)
@@ -84,6 +85,7 @@ def build(spec: SceneSpec, device: int | None = None) -> BuiltScene:
         chunk_shape_in_pixels=list(spec.chunk_shapes),
         device=device,
         ring_storage=spec.ring_storage,
+        blocked_twin=spec.blocked_twin,
     )
     vol.world.position = spec.world_position
     vol.world.scale = spec.world_scale
@@ -279,3 +281,37 @@ def expected_single_voxel_pixel(offset_xyz=(0, 5, 0), frame: int = 65, distance:
     col = (frame - 1) / 2.0 - offset_xyz[2] / (depth * per_pixel)
     row = (frame - 1) / 2.0 - offset_xyz[1] / (depth * per_pixel)
     return row, col
+
+
+# ---------------------------------------------------------------------------
+# micro-block copy of a density ring (svr_lod_desc::blocked_twin)
+# ---------------------------------------------------------------------------
+def micro_blocks_of(ring: np.ndarray) -> np.ndarray:
+    """What the micro-block copy of a density ring [z][y][x] must hold (flat): 128-byte blocks of 8x4x4 (1-byte voxels),
+    4x4x4 (2-byte) or 4x4x2 (4-byte) slots in [bz][by][bx] order, the slots of a block in [z][y][x] order (include/svr.h)."""
+    xb, yb, zb = {1: (8, 4, 4), 2: (4, 4, 4), 4: (4, 4, 2)}[ring.dtype.itemsize]
+    rz, ry, rx = ring.shape
+    v = ring.reshape(rz // zb, zb, ry // yb, yb, rx // xb, xb)
+    return np.ascontiguousarray(v.transpose(0, 2, 4, 1, 3, 5)).reshape(-1)
+
+
+def read_micro_block_copy(rings, lod: int):
+    """The micro-block copy of LOD `lod` as it lies in HBM (flat numpy array of the ring's element type), or None."""
+    import ctypes as C
+
+    import torch
+
+    from . import _native as N
+
+    twin = C.c_void_p()
+    N.check(N.lib().svr_lod_twin_ptr(rings.handle, lod, C.byref(twin)), "svr_lod_twin_ptr")
+    if not twin.value:
+        return None
+    N.check(N.lib().svr_sync(rings.handle), "svr_sync")
+    dt = {"uint8": np.uint8, "uint16": np.uint16}.get(rings.density_storage, np.float32)
+    n = int(np.prod(rings.ring_shapes[lod]))
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (n * np.dtype(dt).itemsize,), "typestr": "|u1", "data": (twin.value, False), "version": 2}
+
+    return torch.as_tensor(_Raw(), device="cuda").cpu().numpy().view(dt).copy()

@@ -243,3 +243,20 @@ def test_host_codec_header_symbols_are_exported_and_the_header_is_plain_c(tmp_pa
     strict = ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only"]
     subprocess.run([gcc, "-std=c99", *strict, str(unit)], check=True)
     subprocess.run([gxx, "-std=c++17", *strict, "-x", "c++", str(unit)], check=True)
+
+
+def test_blocked_twin_argument():
+    from sub_volume_renderer_amd._wrapping_buffer import blocked_twin_lods
+
+    shapes = [(64, 64, 64), (32, 32, 32), (30, 32, 32), (32, 32, 36)]                # numpy order: the last two do not fit
+    assert blocked_twin_lods(shapes, "auto") == [True, False, False, False]
+    assert blocked_twin_lods(shapes[2:], "auto") == [False, False]
+    assert blocked_twin_lods(shapes, True) == [True, True, False, False]
+    assert blocked_twin_lods(shapes, False) == [False] * 4
+    assert blocked_twin_lods(shapes, [False, True, False, False]) == [False, True, False, False]
+    with pytest.raises(ValueError):
+        blocked_twin_lods(shapes, [True, True, True, False])
+    with pytest.raises(ValueError):
+        blocked_twin_lods(shapes, [True])
+    with pytest.raises(ValueError):
+        blocked_twin_lods(shapes, "always")

@@ -136,3 +136,33 @@ def test_large_region_is_split_over_staging_slots():
     buf.load_logical_roi(Roi((0, 0, 0), (256, 256, 256)))
     np.testing.assert_array_equal(buf.texture.data[:256], data[:256].astype(np.float32))
     np.testing.assert_array_equal(buf.segmentations_texture.data[:256], seg[:256])
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32], ids=lambda d: np.dtype(d).name)
+def test_micro_block_copy_follows_the_ring_through_wrapped_loads(dtype):
+    """svr_lod_desc::blocked_twin: after every load — chunk-aligned ones through the 16-voxel streaming scatter, odd ones
+    through the per-voxel scatter, windows that wrap around the ring — the micro-block copy holds exactly the ring's
+    elements at svr_blocked_index's places; and a cleared ring clears its copy."""
+    from sub_volume_renderer_amd.testing import micro_blocks_of, read_micro_block_copy
+
+    rng = np.random.default_rng(7)
+    shape = (96, 80, 160)
+    data = (rng.integers(1, 255, shape).astype(dtype) if dtype != np.float32 else rng.standard_normal(shape).astype(np.float32))
+    seg = rng.integers(0, 2 ** 31, shape, dtype=np.uint32)
+    for chunk, ring in (((4, 4, 16), (6, 5, 4)), ((2, 2, 4), (10, 6, 6))):          # rings 24x20x64 and 20x12x24 voxels (z, y, x)
+        buf = WrappingBuffer(data, seg, Coordinate(ring), Coordinate(chunk))
+        assert buf.rings.blocked_twin == [True]
+        ring_px = tuple(int(v) for v in buf.shape_in_pixels)
+        for off in ((0, 0, 0), (8, 4, 16), (40, 36, 80), (70, 60, 130), (33, 27, 51), (0, 0, 0)):
+            # (one chunk short of the ring: an offset off the chunk grid snaps outwards by up to a chunk)
+            want = tuple(min(r - c, s - o) for r, c, s, o in zip(ring_px, chunk, shape, off))
+            buf.load_logical_roi(Roi(off, want))
+            tex = buf.texture.data                                       # float32 view of the ring (values exact)
+            twin = read_micro_block_copy(buf.rings, 0)
+            np.testing.assert_array_equal(twin, micro_blocks_of(tex.astype(twin.dtype)))
+            assert np.count_nonzero(twin) > 0
+    import ctypes as C
+
+    from sub_volume_renderer_amd import _native as N
+    N.check(N.lib().svr_clear_lod(buf.rings.handle, 0), "svr_clear_lod")
+    assert np.count_nonzero(read_micro_block_copy(buf.rings, 0)) == 0 and np.count_nonzero(buf.texture.data) == 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time (HIP events, svr_time_render) of the C2 / C5 frame from one view, full and LMIP mode.
-usage: exp_view_ms.py [camera K1|K2|-x|-y|-z|diag] [ring storage native|float32] [config C2|C5]"""
+usage: exp_view_ms.py [camera K1|K2|-x|-y|-z|diag] [ring storage native|float32] [config C2|C5] [twin|notwin]"""
 import ctypes as C
 import os
 import sys
@@ -13,8 +13,9 @@ from sub_volume_renderer_amd import _native as N  # noqa: E402
 cam = sys.argv[1] if len(sys.argv) > 1 else "K1"
 storage = sys.argv[2] if len(sys.argv) > 2 else "native"
 config = sys.argv[3] if len(sys.argv) > 3 else "C2"
+twin = (sys.argv[4] if len(sys.argv) > 4 else "twin") == "twin"      # LOD 0 also kept in micro-blocks (the default)
 W, H = 1920, 1080
-scene, spec = build_scene(config, None, cam, storage, W, H)
+scene, spec = build_scene(config, None, cam, storage, W, H, blocked_twin="auto" if twin else False)
 vol = scene.volume
 r = vol.render(scene.camera, W, H)
 out = []
@@ -30,4 +31,4 @@ for mode in ("full", "lmip"):
         N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), 10, C.byref(ms)), "time")
         vals.append(ms.value)
     out.append(sorted(vals)[1])
-print(f"{config} {storage:8s} {cam:5s} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms", flush=True)
+print(f"{config} {storage:8s} {cam:5s} {'twin  ' if twin else 'notwin'} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms", flush=True)

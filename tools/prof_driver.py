@@ -15,7 +15,7 @@ from sub_volume_renderer_amd import _native as N, synth, testing  # noqa: E402
 from sub_volume_renderer_amd.pyramid import build_pyramid  # noqa: E402
 
 
-def build_scene(config="C2", n=None, camera="K1", ring_storage="native", W=1920, H=1080):
+def build_scene(config="C2", n=None, camera="K1", ring_storage="native", W=1920, H=1080, blocked_twin="auto"):
     """The bench's scene for `config` (bench.py builds it the same way), camera K1 / K2 or one of the axis views."""
     n = n or {"C2": 1024, "C5": 2048}[config]
     dev = torch.device("cuda", 0)
@@ -33,6 +33,7 @@ def build_scene(config="C2", n=None, camera="K1", ring_storage="native", W=1920,
         spec.cam_position = tuple(np.array([c, c, c]) + 1.6 * n * d)
         spec.cam_target = (c, c, c)
     spec.ring_storage = ring_storage
+    spec.blocked_twin = blocked_twin
     return testing.build(spec), spec
 
 
@@ -45,8 +46,9 @@ if __name__ == "__main__":
     ap.add_argument("camera", nargs="?", default="K1")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--ring-storage", default="native")
+    ap.add_argument("--no-blocked-twin", action="store_true", help="rings in rows only (no micro-block copy of LOD 0)")
     a = ap.parse_args()
-    scene, spec = build_scene(a.config, a.n, a.camera, a.ring_storage)
+    scene, spec = build_scene(a.config, a.n, a.camera, a.ring_storage, blocked_twin=False if a.no_blocked_twin else "auto")
     vol = scene.volume
     N.check(N.lib().svr_set_variant(vol._rings.handle, int(a.variant, 0)), "variant")
     vol.material.lmip_threshold = float("inf") if a.mode == "full" else float(spec.material["lmip_threshold"])
