@@ -342,7 +342,8 @@ int  svr_debug_counters(svr_ctx* ctx, uint32_t out[8], int reset);
 /* diagnostics: shader-clock cycles of wave residency per kernel section, summed over the waves of the
  * instrumented renders: [0] prologue (ray set-up, event search), [1] span refresh + run length, [2] general
  * batches, [3] brick slab set-up + load issue, [4] wait for the brick loads, [5] brick batches, [6] direct
- * batches, [7] epilogue (shading, stores); [8..15] finer splits used while tuning (see march_kernel.hip) */
+ * batches, [7] epilogue (shading, stores); [8..14] finer splits used while tuning (see march_kernel.hip);
+ * [15] is a COUNT, not cycles: the direct batches that gathered from a micro-block copy (svr_lod_desc::blocked_twin) */
 int  svr_debug_timers(svr_ctx* ctx, uint64_t out[16], int reset);
 
 /* timing helper: run `iters` back-to-back renders on the context's render

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "svr_internal.h"
 
@@ -455,22 +456,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint3
 template <typename LodT>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const LodT& L, uint32_t p) { return part_rsrc(L, p, L.rbase); }
 
-// Micro-block copy of a ring (svr_lod_desc::blocked_twin; host: svr_blocked_index): 128-byte blocks of
-// 2^XB x 2^YB x 2^ZB slots in [bz][by][bx] order, the slots of a block in [z][y][x] order.
-template <int ESH> struct TwinBlock { static constexpr int XB = ESH == 0 ? 3 : 2, YB = 2, ZB = ESH == 2 ? 1 : 2; };
-// Byte offset of the texel of voxel (x, y, z) in that copy, for a lane whose ring slot is voxel + (kx, ky, kz) with
-// constants that are multiples of the ring extents — and therefore of the block extents: the block coordinates of the
-// slot are those of the voxel plus constants, the position inside the block is the voxel's own low bits.  Kb = the
-// constants' part of the block number (+ the copy's offset in the resource, in blocks); all mod 2^32.
-template <int ESH>
-__device__ __forceinline__ uint32_t twin_offset(uint32_t x, uint32_t y, uint32_t z, int nbx, int nby, uint32_t Kb) {
-    typedef TwinBlock<ESH> B;
-    const int bx = (int)x >> B::XB, by = (int)y >> B::YB, bz = (int)z >> B::ZB;        // (arithmetic: a voxel index may be negative)
-    const int blk = __mul24(__mul24(bz, nby) + by, nbx) + bx;
-    const uint32_t inb = ((((z & ((1u << B::ZB) - 1u)) << B::YB) | (y & 3u)) << B::XB) | (x & ((1u << B::XB) - 1u));
-    return (((uint32_t)blk + Kb) << 7) | (inb << ESH);
-}
-
 // Raw texel as fetched: f32 rings (ESH = 2) hold the sample itself, u8 rings (ESH = 0) the byte,
 // widened to f32 (exactly) only where the LMIP state machine needs the value.
 template <int ESH> struct Texel { typedef float type; };
@@ -521,6 +506,26 @@ __device__ __forceinline__ uint32_t shl_add_c(uint32_t a, uint32_t c) {         
     uint32_t r;
     asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
     return r;
+}
+
+// Micro-block copy of a ring (svr_lod_desc::blocked_twin; host: svr_blocked_index): 128-byte blocks of
+// 2^XB x 2^YB x 2^ZB slots in [bz][by][bx] order, the slots of a block in [z][y][x] order.
+template <int ESH> struct TwinBlock { static constexpr int XB = ESH == 0 ? 3 : 2, YB = 2, ZB = ESH == 2 ? 1 : 2; };
+// Byte offset of the texel of voxel (x, y, z) in that copy, for a lane whose ring slot is voxel + (kx, ky, kz) with
+// constants that are multiples of the ring extents — and therefore of the block extents: the block coordinates of the
+// slot are those of the voxel plus constants, the position inside the block is the voxel's own low bits.  Kb = the
+// constants' part of the block number (+ the copy's offset in the resource, in blocks); all mod 2^32.
+template <int ESH>
+__device__ __forceinline__ uint32_t twin_offset(uint32_t x, uint32_t y, uint32_t z, int nbx, int nby, uint32_t Kb) {
+    typedef TwinBlock<ESH> B;
+    const int bx = (int)x >> B::XB, by = (int)y >> B::YB, bz = (int)z >> B::ZB;        // (arithmetic: a voxel index may be negative)
+    // (written out: from `__mul24(bz, nby) + by` the compiler makes a v_mad_u64_u32, a quarter-rate instruction)
+    // (voxel indices are non-negative below 2^23 on this path, like the row-major form's: MarchParams::lod_pow2)
+    // (builtins, not the asm mad24 of the row-major form: with even one asm statement here the kernel takes 101 VGPRs instead
+    //  of 92 — one wave per SIMD less; the price is a v_mad_u64_u32 for the inner multiply-add)
+    const uint32_t blk = __umul24(__umul24((uint32_t)bz, (uint32_t)nby) + (uint32_t)by, (uint32_t)nbx) + (uint32_t)bx;
+    const uint32_t inb = ((((z & ((1u << B::ZB) - 1u)) << B::YB) | (y & 3u)) << B::XB) | (x & ((1u << B::XB) - 1u));
+    return ((blk + Kb) << 7) | (inb << ESH);
 }
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -885,6 +890,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
         const bool use_brick = P.brick >= 2 || lines * 16 > P.brick_lines * quads;   // lookups per full wave-load
         brick_mode = use_brick ? 1 + P.slab_long : 0;
         many_lines = use_brick;
+        // (tried: keep the bricks for waves whose rays all run along the ring's rows, |dx| > 4 max(|dy|, |dz|) — it takes the
+        //  -x view of C2 from +6 % to +1.5 % against rings without a copy, and costs K1 2.5 % and C5's -x view its 7 % gain)
     }
     const int wave_lds = wave * P.brick_bytes;
 
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         const uint32_t ky = (uint32_t)L.addw[1] - (py ? L.ring[1] : 0u);
                         const uint32_t kz = (uint32_t)L.addw[2] - (pz ? L.ring[2] : 0u);
                         Kc = (kz * L.ring[1] + ky) * L.rx4 + (kx << ESH) + L.base_bytes;  // mod 2^32
-                        if (many_lines && L.twin) {
+                        if (many_lines && L.twin) {                           // (wave-uniform)
                             typedef TwinBlock<ESH> B;
                             Kb = (uint32_t)(((int)kz >> B::ZB) * (int)(L.ring[1] >> B::YB) + ((int)ky >> B::YB)) * (L.ring[0] >> B::XB) +
                                  (uint32_t)((int)kx >> B::XB) + (L.twin_base_bytes >> 7);
@@ -1042,9 +1049,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             const bool ring_split = BIG && L.nparts > 1u;                // wave-uniform
             // this wave's gathers on this LOD go to the micro-block copy of the ring (and it stages no bricks from the ring)
             const bool use_twin = many_lines && L.twin != 0u;
-            const void* const gather_base = use_twin ? L.twin_rbase : L.rbase;
-            __amdgpu_buffer_rsrc_t rsrc_g = rsrc;
-            if constexpr (BIG) { if (use_twin) rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.rbytes, 0x00020000); }
+            __amdgpu_buffer_rsrc_t rsrc_twin = rsrc;              // (one resource for everything: the copy's offset is part of Kb)
+            if constexpr (BIG) { if (use_twin) rsrc_twin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.rbytes, 0x00020000); }
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
             // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
@@ -1270,14 +1276,17 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             }
 
             // ---- direct fast batches: texel offset = ((iz*Ry + iy)*Rx + ix)*es + Kc, U loads in flight
+            // (two copies of the loop, one per layout the wave gathers from: each keeps only its own constants live)
+            auto direct_batches = [&](auto from_twin) {
+            constexpr bool TW = decltype(from_twin)::value;
             for (; run > 0; --run) {
                 const bool live = alive && !finished && n < nsteps;
                 if (__builtin_amdgcn_ballot_w64(live) == 0) break;
-                if (COUNT) ++c_direct;
+                if (COUNT) { ++c_direct; if (TW) t_acc[15] += 1ull; }          // ([15]: a count, not cycles — svr_debug_timers)
                 texel_t s[U];
                 uint32_t off[U];
                 float2_t iter = { (float)n, (float)n + 1.0f };
-                if (use_twin) {
+                if constexpr (TW) {
                     const int nbx = (int)(L.ring[0] >> TwinBlock<ESH>::XB), nby = (int)(L.ring[1] >> TwinBlock<ESH>::YB);
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
@@ -1313,7 +1322,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t pa = part_of((int)ez2.x), pb = part_of((int)ez2.y);
                     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pa, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(live)));
                     if (__builtin_amdgcn_ballot_w64(live && (pa != p0 || pb != p0)) == 0) {
-                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0, gather_base);
+                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0, TW ? L.twin_rbase : L.rbase);
                         const uint32_t sub = p0 * L.part_bytes;
 #pragma unroll
                         for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rp, live ? off[u] - sub : 0xFFFFFFFFu);
@@ -1333,7 +1342,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             for (unsigned long long todo = __builtin_amdgcn_ballot_w64(live); todo != 0ull;) {
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
                                 const bool mine = live && part == p;
-                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p, gather_base), mine ? rel : 0xFFFFFFFFu);
+                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p, TW ? L.twin_rbase : L.rbase), mine ? rel : 0xFFFFFFFFu);
                                 a = mine ? t : a;
                                 todo &= ~__builtin_amdgcn_ballot_w64(mine);
                             }
@@ -1344,12 +1353,14 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 } else
                 if (live) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rsrc_g, off[u]);
+                    for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(TW ? rsrc_twin : rsrc, off[u]);
                 }
                 if (__builtin_amdgcn_ballot_w64(live && n + U > nsteps) != 0) lmip_batch(s, n, live, true);
                 else lmip_batch(s, n, live, false);
                 n += U;
             }
+            };
+            if (use_twin) direct_batches(std::true_type{}); else direct_batches(std::false_type{});
             } while (held > 0 && __builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) != 0);
             lap(6);
         }

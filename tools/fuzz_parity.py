@@ -142,7 +142,7 @@ def main():
     kernel = ([a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("kernel=")] or ["both"])[0]
     assert kernel in ("both", "production", "instrumented"), kernel
     runs = {"both": (False, True), "production": (False,), "instrumented": (True,)}[kernel]
-    bricks = 0
+    bricks = twins = 0
     bad = skipped = hits = 0
     for seed in range(first, first + cases):
         if (seed - first) % 1000 == 999:                     # long campaigns: a sign of life once a minute or so
@@ -171,6 +171,9 @@ def main():
             if counted:
                 N.lib().svr_debug_counters(scene.volume._rings.handle, dbg, 1)
                 bricks += dbg[2] > 0
+                tm = (C.c_uint64 * 16)()
+                N.lib().svr_debug_timers(scene.volume._rings.handle, tm, 1)
+                twins += tm[15] > 0                                   # batches gathered from the micro-block copy of a ring
             rep = testing.compare(res, ref)
             pick_ok = bool(np.array_equal(res.pick.cpu().numpy().view(np.uint64), ref.pick))
             this_ok = (rep["flags_equal"] and rep["labels_equal"] and rep.get("steps_equal", True) and pick_ok
@@ -183,7 +186,7 @@ def main():
         bad += not ok
         del scene
     print(f"fuzz{' (brick-biased)' if brick else ''} kernel={kernel}: {cases} cases from seed {first}: {bad} mismatching, {skipped} rejected by both, "
-          f"{hits} with hits, {bricks} staged LDS bricks", flush=True)
+          f"{hits} with hits, {bricks} staged LDS bricks, {twins} gathered from a micro-block copy", flush=True)
     sys.exit(1 if bad else 0)
 
 
