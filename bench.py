@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
                     help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
+    ap.add_argument("--no-blocked-twin", action="store_true",
+                    help="density rings in rows only: no micro-block copy of the finest LOD (svr_lod_desc::blocked_twin; A/B)")
     ap.add_argument("--float32-block", action="store_true", help="C5: measure the float32-ring block too (C2 does by default)")
     ap.add_argument("--no-float32-block", action="store_true",
                     help="C2 / C5 at N = 1 with native rings: skip the second measurement of the same workload on float32 rings "
@@ -334,6 +336,8 @@ def main():
             spec.material.update(lmip_threshold=spec.material["lmip_threshold"] * scale16, clim=(0.0, 255.0 * scale16))
     t_gen = time.time() - t0
     spec.ring_storage = args.ring_storage
+    if args.no_blocked_twin:
+        spec.blocked_twin = False
 
     def source_stats(reset=False):
         """(seconds inside the backing arrays' reads, decoded bytes handed out, stored bytes read) since the last reset:
@@ -534,7 +538,7 @@ def main():
         tools/profile_bench.sh: rocprofv3 cannot run from inside the process it profiles), or a note why there are none."""
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
         here = dict(config=cfg, n=n, width=W, height=H, camera=camera, variant=args.variant,
-                    ring_storage=ring_storage, kernel_source_sha16=kernel_source_hash())
+                    ring_storage=ring_storage, blocked_twin=not args.no_blocked_twin, kernel_source_sha16=kernel_source_hash())
         if not os.path.exists(tpath):
             return None, None
         with open(tpath) as f:
@@ -650,6 +654,7 @@ def main():
                                  "cost-sorted per camera (policy 0, default) for `sequential` and `roofline`"
                                  if (loop.F > 1 and not (args.variant >> 13) & 7) else "as --variant says (0: cost-sorted per camera)",
                     "ring_storage": vol._rings.density_storage,
+                    "blocked_twin": list(vol._rings.blocked_twin),      # LODs whose density ring is also kept in 128-byte micro-blocks
                 },
             }
             for k in ("spread", "sequential", "lmip", "roofline"):
@@ -664,6 +669,7 @@ def main():
                 and args.source_dtype == "uint8" and vol._rings.density_storage != "float32"):
             spec32 = (config5_spec if cfg == "C5" else config2_spec)(n, W, H, camera, pairs)
             spec32.ring_storage = "float32"
+            spec32.blocked_twin = spec.blocked_twin
             t0 = time.time()
             scene32 = testing.build(spec32, device=local_rank)
             scene32.volume.synchronize()
@@ -779,6 +785,7 @@ def main():
                     "ray_steps_total": int(sum(path_steps)),
                     "parallelism": "single" if not collective else f"{args.tiling} x{world} via {transport}",
                     "kernel_variant": args.variant, "frames_in_flight": 1, "ring_storage": vol._rings.density_storage,
+                    "blocked_twin": list(vol._rings.blocked_twin),
                 },
                 "frame_ms": r["frame_ms"], "upload": r["upload"],
                 "initial_fill": {"staged_bytes": fill_bytes, "seconds_in_upload_calls": round(fill_seconds, 3),

@@ -45,6 +45,7 @@ doc = {
               f"march_span dispatch over {nf} / {nw} dispatches; tools/profile_bench.sh",
     "workload": {"config": "C2", "n": 1024, "width": 1920, "height": 1080, "camera": "K1",
                  "variant": cfgd["kernel_variant"], "ring_storage": cfgd["ring_storage"],
+                 "blocked_twin": bool(cfgd.get("blocked_twin", [False])[0]),
                  "kernel_source_sha16": bench.kernel_source_hash()},
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> x2 "
