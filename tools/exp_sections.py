@@ -48,9 +48,9 @@ def main():
             torch.cuda.synchronize()
             N.lib().svr_debug_timers(h, tm, 1)
             N.lib().svr_debug_counters(h, dbg, 1)
-            tot = max(1, sum(tm))
-            tline = " ".join(f"{nm}={100 * t / tot:.1f}%" for nm, t in zip(NAMES, tm) if t)
-            cline = " ".join(f"{nm}={v}" for nm, v in zip(CENSUS, dbg))
+            tot = max(1, sum(tm[:15]))                                  # ([15] is a count: direct batches served by a micro-block copy)
+            tline = " ".join(f"{nm}={100 * t / tot:.1f}%" for nm, t in zip(NAMES[:15], tm) if t)
+            cline = " ".join(f"{nm}={v}" for nm, v in zip(CENSUS, dbg)) + f" direct_from_micro_blocks={tm[15]}"
             steps = r.steps.to(torch.int64)
             r = vol.render(cam, W, H, region=reg)
             vol.prepare()
