@@ -528,6 +528,31 @@ __device__ __forceinline__ uint32_t twin_offset(uint32_t x, uint32_t y, uint32_t
     return ((blk + Kb) << 7) | (inb << ESH);
 }
 
+// The same from the packed form of the voxel (x, yz = y | z << 16, both below 2^16: LodParams::twin says so) in 8 VALU
+// operations (byte rings; 9 otherwise) where the plain form takes 12:
+//   offset = 4row * (NBx * 32) + (x & ~xm) << (7 - XB)  +  [ (y & 3) * wy + (z & zm) * wz + ((x & xm) << ESH | KbS) ]
+// with 4row = (y & ~3) + (z & ~zm) * (NBy * 4 >> ZB) from one v_dot2_u32_u16, the bracket from another (wy, wz: the byte
+// strides of y and z inside a block) and KbS = Kb << 7 (its low 7 bits are free for the in-block part).
+struct TwinConsts { uint32_t row_w, inb_w, nbx32; };           // wave-uniform: (1 | NBy * 4 >> ZB << 16), (wy | wz << 16), NBx * 32
+template <int ESH>
+__device__ __forceinline__ TwinConsts twin_consts(uint32_t Rx, uint32_t Ry) {
+    typedef TwinBlock<ESH> B;
+    TwinConsts c;
+    c.row_w = 1u | (((Ry >> B::YB) * (4u >> B::ZB)) << 16);
+    c.inb_w = (1u << (B::XB + ESH)) | ((1u << (B::XB + B::YB + ESH)) << 16);
+    c.nbx32 = (Rx >> B::XB) * 32u;
+    return c;
+}
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+template <int ESH>
+__device__ __forceinline__ uint32_t twin_offset_packed(uint32_t x, uint32_t yz, const TwinConsts& c, uint32_t KbS) {
+    typedef TwinBlock<ESH> B;
+    constexpr uint32_t xm = (1u << B::XB) - 1u, zm = (1u << B::ZB) - 1u, low = 3u | (zm << 16);
+    const uint32_t xin = ESH == 0 ? ((x & xm) | KbS) : (((x & xm) << ESH) | KbS);
+    const uint32_t inb = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, yz & low), __builtin_bit_cast(ushort2_t, c.inb_w), xin, false);
+    const uint32_t row4 = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, yz & ~low), __builtin_bit_cast(ushort2_t, c.row_w), 0u, false);
+    return __umul24(row4, c.nbx32) + (((x & ~xm) << (7 - B::XB)) + inb);
+}
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
@@ -1287,13 +1312,14 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 uint32_t off[U];
                 float2_t iter = { (float)n, (float)n + 1.0f };
                 if constexpr (TW) {
-                    const int nbx = (int)(L.ring[0] >> TwinBlock<ESH>::XB), nby = (int)(L.ring[1] >> TwinBlock<ESH>::YB);
+                    const TwinConsts tc = twin_consts<ESH>(L.ring[0], L.ring[1]);
+                    const uint32_t KbS = Kb << 7;
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
-                        const Idx2 v = voxel_pair(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
+                        const Idx2p v = voxel_pair_packed(Rsx, Rsy, Rsz, Rtx, Rty, Rtz, iter, ssx, ssy, ssz);
                         iter += 2.0f;
-                        off[u] = twin_offset<ESH>(v.x0, v.y0, v.z0, nbx, nby, Kb);
-                        off[u + 1] = twin_offset<ESH>(v.x1, v.y1, v.z1, nbx, nby, Kb);
+                        off[u] = twin_offset_packed<ESH>(v.x0, v.yz0, tc, KbS);
+                        off[u + 1] = twin_offset_packed<ESH>(v.x1, v.yz1, tc, KbS);
                     }
                 } else {
 #pragma unroll

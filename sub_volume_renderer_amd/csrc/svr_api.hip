@@ -1062,7 +1062,8 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
         Q.nparts = 1u; Q.zsplit = Q.ring[2]; Q.part_bytes = 0u; Q.rbytes_last = 0u;
         // the micro-block copy of the ring (svr_lod_desc::blocked_twin): inside the one resource, or a resource of its own
         // that is cut into parts exactly like the ring's (parts of whole blocks: zsplit is a multiple of 4 planes)
-        Q.twin = c->lod[l].twin ? 1u : 0u;
+        // (the march addresses it from the packed voxel index y | z << 16: both below 2^16, whatever the ray)
+        Q.twin = (c->lod[l].twin && P.size[1] * Q.scale[1] < 65536.0f && P.size[2] * Q.scale[2] < 65536.0f) ? 1u : 0u;
         Q.twin_base_bytes = (!P.per_lod_rsrc && c->lod[l].twin)
                                 ? (uint32_t)(static_cast<const char*>(c->lod[l].twin) - static_cast<const char*>(c->density_all)) : 0u;
         Q.twin_rbase = P.per_lod_rsrc ? c->lod[l].twin : c->density_all;

@@ -17,6 +17,8 @@ twin = (sys.argv[4] if len(sys.argv) > 4 else "twin") == "twin"      # LOD 0 als
 W, H = 1920, 1080
 scene, spec = build_scene(config, None, cam, storage, W, H, blocked_twin="auto" if twin else False)
 vol = scene.volume
+variant = int(os.environ.get("EXP_VARIANT", "0"), 0)                   # svr_set_variant bits for the run (include/svr.h)
+N.check(N.lib().svr_set_variant(vol.prepare(), variant), "svr_set_variant")
 r = vol.render(scene.camera, W, H)
 out = []
 for mode in ("full", "lmip"):
@@ -31,4 +33,4 @@ for mode in ("full", "lmip"):
         N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), 10, C.byref(ms)), "time")
         vals.append(ms.value)
     out.append(sorted(vals)[1])
-print(f"{config} {storage:8s} {cam:5s} {'twin  ' if twin else 'notwin'} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms", flush=True)
+print(f"{config} {storage:8s} {cam:5s} {'twin  ' if twin else 'notwin'} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms" + (f"   variant {variant:#x}" if variant else ""), flush=True)
