@@ -151,6 +151,7 @@ int main(int argc, char** argv) {
     svr_lod_desc lods[2];
     memset(lods, 0, sizeof(lods));
     for (int k = 0; k < 2; ++k) { lods[k].ring_dims[0] = lods[k].ring_dims[1] = lods[k].ring_dims[2] = 32; lods[k].density_storage = SVR_U8; }
+    lods[0].blocked_twin = 1;       /* the finest ring also in 128-byte micro-blocks: waves pick the copy that suits their view (svr.h) */
     svr_ctx* ctx = NULL;
     CHECK(svr_create(0, 2, lods, &ctx));
 

@@ -48,6 +48,7 @@ class DeviceRings:
         # "auto" = the finest one when its extents allow (multiples of (8, 4, 4) in x, y, z), True = every LOD whose
         # extents allow, False = none, or one bool per LOD (an extent that does not allow it is a ValueError then).
         self.blocked_twin = blocked_twin_lods(self.ring_shapes, blocked_twin)
+        self._twin_optional = isinstance(blocked_twin, str)      # "auto": the copy is given up when the device has no room for it
         self._handle = None
         self._closed = False
 
@@ -70,7 +71,14 @@ class DeviceRings:
 
                 device = torch.cuda.current_device()
             h = C.c_void_p()
-            N.check(lib.svr_create(int(device), len(descs), descs, C.byref(h)), "svr_create")
+            status = lib.svr_create(int(device), len(descs), descs, C.byref(h))
+            if status == -3 and self._twin_optional and any(self.blocked_twin):
+                # no room for rings + copy (SVR_ERR_NOMEM): the copy is an optimisation, the rings are not
+                for d in descs:
+                    d.blocked_twin = 0
+                self.blocked_twin = [False] * len(self.ring_shapes)
+                status = lib.svr_create(int(device), len(descs), descs, C.byref(h))
+            N.check(status, "svr_create")
             self._handle = h
             self.device = int(device)
         return self._handle

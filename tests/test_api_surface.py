@@ -260,3 +260,37 @@ def test_blocked_twin_argument():
         blocked_twin_lods(shapes, [True])
     with pytest.raises(ValueError):
         blocked_twin_lods(shapes, "always")
+
+
+def test_auto_twin_is_given_up_when_the_device_has_no_room(monkeypatch):
+    """`blocked_twin="auto"`: SVR_ERR_NOMEM from svr_create with the copy is answered by creating the rings without it;
+    an explicit request is not second-guessed (MemoryError)."""
+    from sub_volume_renderer_amd._wrapping_buffer import DeviceRings
+
+    calls = []
+
+    class FakeLib:
+        def svr_create(self, device, n, descs, out):
+            twins = [int(descs[i].blocked_twin) for i in range(n)]
+            calls.append(twins)
+            if any(twins):
+                return -3
+            out._obj.value = 0x1234
+            return 0
+
+        def svr_last_error(self):
+            return b"svr_create: out of device memory for ring textures"
+
+        def svr_destroy(self, h):
+            return 0
+
+    monkeypatch.setattr(_native, "lib", lambda: FakeLib())
+    rings = DeviceRings([(64, 64, 64), (32, 32, 32)], device=0, density_storage="uint8")
+    assert rings.blocked_twin == [True, False]
+    assert rings.handle.value == 0x1234
+    assert calls == [[1, 0], [0, 0]] and rings.blocked_twin == [False, False]
+    calls.clear()
+    wanted = DeviceRings([(64, 64, 64)], device=0, density_storage="uint8", blocked_twin=True)
+    with pytest.raises(MemoryError):
+        wanted.handle
+    assert calls == [[1]]
