@@ -434,6 +434,16 @@ def test_a_single_float_ring_beyond_4_gib_is_reached_through_several_resources()
             ref = lmip.render_spec(small)
             _assert_frame(res, ref, ("float ring beyond 4 GiB", z_centre, view))
             assert (ref.flags == 2).sum() > 200
+            # ... and with every wave sent to the micro-block copy of that ring (8.86 GB more, cut into the same three parts)
+            assert scene.volume._rings.blocked_twin[0]
+            N.check(N.lib().svr_set_variant(scene.volume.prepare(), 0x200), "svr_set_variant")
+            timers = (C.c_uint64 * 16)()
+            N.check(N.lib().svr_debug_timers(scene.volume._rings.handle, timers, 1), "svr_debug_timers")
+            res = testing.render_both(scene.volume, spec.camera(), spec.width, spec.height)
+            N.check(N.lib().svr_debug_timers(scene.volume._rings.handle, timers, 1), "svr_debug_timers")
+            assert timers[15] > 0, "no batch gathered from the copy"
+            _assert_frame(res, ref, ("micro-block copy of a float ring beyond 4 GiB", z_centre, view))
+            N.check(N.lib().svr_set_variant(scene.volume.prepare(), 0), "svr_set_variant")
     scene.volume.close()
 
 

@@ -41,7 +41,11 @@ def report(name, ms, nbytes):
 n = 1024
 d = torch.randint(0, 255, (n // 2, n // 2, 528), dtype=torch.uint8, device=dev)
 l = torch.randint(0, 2 ** 31 - 1, (n // 2, n // 2, 528), dtype=torch.int32, device=dev)
-buf = WrappingBuffer(d, l, (32, 32, 11), (16, 16, 48))
+# (EXP_NO_TWIN=1: rows only, without the micro-block copy every upload of the finest ring writes too)
+from sub_volume_renderer_amd._wrapping_buffer import DeviceRings  # noqa: E402
+rings = DeviceRings([(512, 512, 528)], density_storage="uint8", blocked_twin=os.environ.get("EXP_NO_TWIN") is None)
+buf = WrappingBuffer(d, l, (32, 32, 11), (16, 16, 48), _rings=rings, _lod=0)
+print("micro-block copy of the ring:", rings.blocked_twin, flush=True)
 lib, h = N.lib(), buf.rings.handle
 
 
