@@ -67,15 +67,19 @@ typedef struct svr_lod_desc {
                                       ring is allocated (4 of the 5 bytes per slot), uploads must pass labels = NULL,
                                       every hit gets label 0 (-> colors[0], like unlabelled voxels: FUTURE.md:170-176).
                                       All LODs of a context alike. */
-    int32_t blocked_twin;          /* 1: keep a SECOND copy of this LOD's density ring, laid out in 128-byte micro-blocks that
+    int32_t blocked_twin;          /* 1 or 2: keep a SECOND copy of this LOD's density ring, laid out in 128-byte micro-blocks that
                                       are compact in 3-D (8 x 4 x 4 one-byte voxels, 4 x 4 x 4 two-byte, 4 x 4 x 2 four-byte;
                                       blocks in [bz][by][bx] order) — the locality a texture unit's tiled 3-D layout gives the
                                       reference's textureLoad (sample_vol.wgsl:24).  Every upload writes both copies; the march
                                       reads the same texels from whichever copy suits a wave's view: waves whose gathers would
                                       touch many 128-byte ROWS per load (the per-wave probe that otherwise stages LDS bricks)
-                                      gather from the micro-blocks instead.  Costs one more density element per voxel of HBM and
-                                      of upload traffic; results are identical.  ring_dims must be multiples of (8, 4, 4), else
-                                      SVR_ERR_INVALID.  Meant for the finest LOD (the Python mirror's "auto" sets it there). */
+                                      gather from the micro-blocks — with 1 INSTEAD of staging bricks from the rows (what pays on
+                                      the finest LOD), with 2 only where the wave stages none (the LOD cannot, or the wave's boxes
+                                      stopped fitting its LDS region: what pays on the coarser LODs).  Costs one more density
+                                      element per voxel of HBM and of upload traffic; results are identical.  The copies have an
+                                      allocation of their own (they never push the rings over the 4 GiB below which one buffer
+                                      resource reaches every LOD).  ring_dims must be multiples of (8, 4, 4), else SVR_ERR_INVALID.
+                                      The Python mirror's "auto": 1 on the finest LOD, 2 on the others, where the extents allow. */
 } svr_lod_desc;
 
 /* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.

@@ -44,9 +44,11 @@ class DeviceRings:
             raise ValueError("density_storage must be 'float32', 'uint8' or 'uint16'")
         self.density_storage = density_storage
         self.labels = bool(labels)            # False: a volume without segmentation, no label rings at all
-        # Which LODs keep a second copy of their density ring in 128-byte micro-blocks (svr_lod_desc::blocked_twin):
-        # "auto" = the finest one when its extents allow (multiples of (8, 4, 4) in x, y, z), True = every LOD whose
-        # extents allow, False = none, or one bool per LOD (an extent that does not allow it is a ValueError then).
+        # Which LODs keep a second copy of their density ring in 128-byte micro-blocks (svr_lod_desc::blocked_twin), and
+        # what for — per LOD 0 (none), 1 (waves whose gathers touch many rows take it INSTEAD of staging bricks) or 2 (only
+        # where such a wave stages no bricks: "fallback").  "auto" = 1 for the finest LOD, 2 for the others, wherever the
+        # extents allow (multiples of (8, 4, 4) in x, y, z); True = 1 for every LOD whose extents allow; False = none; or one
+        # value per LOD (False / True / 2 / "fallback"; an extent that does not allow it is a ValueError then).
         self.blocked_twin = blocked_twin_lods(self.ring_shapes, blocked_twin)
         self._twin_optional = isinstance(blocked_twin, str)      # "auto": the copy is given up when the device has no room for it
         self._handle = None
@@ -64,7 +66,7 @@ class DeviceRings:
                 d.density_storage = {"uint8": N.SVR_U8, "uint16": N.SVR_U16}.get(self.density_storage, N.SVR_F32)
                 d.no_labels = 0 if self.labels else 1
             for d, twin in zip(descs, self.blocked_twin):
-                d.blocked_twin = 1 if twin else 0
+                d.blocked_twin = int(twin)
             device = self.device
             if device is None:
                 import torch
@@ -76,7 +78,7 @@ class DeviceRings:
                 # no room for rings + copy (SVR_ERR_NOMEM): the copy is an optimisation, the rings are not
                 for d in descs:
                     d.blocked_twin = 0
-                self.blocked_twin = [False] * len(self.ring_shapes)
+                self.blocked_twin = [0] * len(self.ring_shapes)
                 status = lib.svr_create(int(device), len(descs), descs, C.byref(h))
             N.check(status, "svr_create")
             self._handle = h
@@ -141,16 +143,17 @@ def _is_device_tensor(a) -> bool:
     return type(a).__module__.split(".")[0] == "torch" and bool(getattr(a, "is_cuda", False))
 
 
-def blocked_twin_lods(ring_shapes, blocked_twin="auto") -> list[bool]:
-    """Per LOD: does its density ring get a micro-block copy?  (ring_shapes in numpy order)"""
+def blocked_twin_lods(ring_shapes, blocked_twin="auto") -> list[int]:
+    """Per LOD: svr_lod_desc::blocked_twin — 0 no micro-block copy of the density ring, 1 a copy that waves take instead of
+    staging bricks, 2 a copy for waves that stage none.  (ring_shapes in numpy order)"""
     fits = [s[2] % 8 == 0 and s[1] % 4 == 0 and s[0] % 4 == 0 for s in ring_shapes]
     if isinstance(blocked_twin, str):
         if blocked_twin != "auto":
-            raise ValueError("blocked_twin must be 'auto', a bool or one bool per LOD")
-        return [i == 0 and ok for i, ok in enumerate(fits)]
+            raise ValueError("blocked_twin must be 'auto', a bool or one value per LOD")
+        return [(1 if i == 0 else 2) if ok else 0 for i, ok in enumerate(fits)]
     if isinstance(blocked_twin, (bool, np.bool_)):
-        return [bool(blocked_twin) and ok for ok in fits]
-    wanted = [bool(v) for v in blocked_twin]
+        return [1 if (blocked_twin and ok) else 0 for ok in fits]
+    wanted = [2 if (v == "fallback" or (v == 2 and v is not True)) else (1 if v else 0) for v in blocked_twin]
     if len(wanted) != len(fits):
         raise ValueError(f"blocked_twin list length ({len(wanted)}) must match number of scales ({len(fits)})")
     for i, (w, ok) in enumerate(zip(wanted, fits)):

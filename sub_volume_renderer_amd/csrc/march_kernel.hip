@@ -661,7 +661,7 @@ struct LodK {
     const void* rbase;
     uint32_t rbytes;
     uint32_t nparts, zsplit, part_bytes, rbytes_last;      // rings of 4 GiB or more: parts of zsplit planes (LodParams)
-    uint32_t twin, twin_base_bytes;                        // micro-block copy of the ring (LodParams::twin)
+    uint32_t twin, twin_rbytes;                            // micro-block copy of the ring (LodParams::twin)
     const void* twin_rbase;
 };
 __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
@@ -673,7 +673,7 @@ __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
     k.rbase = p->lod[l].rbase; k.rbytes = p->lod[l].rbytes;
     k.nparts = p->lod[l].nparts; k.zsplit = p->lod[l].zsplit; k.part_bytes = p->lod[l].part_bytes; k.rbytes_last = p->lod[l].rbytes_last;
-    k.twin = p->lod[l].twin; k.twin_base_bytes = p->lod[l].twin_base_bytes; k.twin_rbase = p->lod[l].twin_rbase;
+    k.twin = p->lod[l].twin; k.twin_rbytes = p->lod[l].twin_rbytes; k.twin_rbase = p->lod[l].twin_rbase;
     return k;
 }
 
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                         if (many_lines && L.twin) {                           // (wave-uniform)
                             typedef TwinBlock<ESH> B;
                             Kb = (uint32_t)(((int)kz >> B::ZB) * (int)(L.ring[1] >> B::YB) + ((int)ky >> B::YB)) * (L.ring[0] >> B::XB) +
-                                 (uint32_t)((int)kx >> B::XB) + (L.twin_base_bytes >> 7);
+                                 (uint32_t)((int)kx >> B::XB);
                         }
                         if constexpr (BIG) zth = (int)L.zsplit - (int)kz;                 // slot plane ic_z + kz >= k * zsplit <=> ic_z >= zth + (k - 1) * zsplit
                         if (ev[l].cx > n) E = min(E, ev[l].cx);
@@ -1073,9 +1073,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             // (a ring of 4 GiB or more comes through nparts resources of L.zsplit planes each: part_rsrc)
             const bool ring_split = BIG && L.nparts > 1u;                // wave-uniform
             // this wave's gathers on this LOD go to the micro-block copy of the ring (and it stages no bricks from the ring)
-            const bool use_twin = many_lines && L.twin != 0u;
-            __amdgpu_buffer_rsrc_t rsrc_twin = rsrc;              // (one resource for everything: the copy's offset is part of Kb)
-            if constexpr (BIG) { if (use_twin) rsrc_twin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.rbytes, 0x00020000); }
+            // (LodParams::twin 1: instead of staging bricks from the ring; 2: only where this wave stages no bricks — a LOD that
+            //  cannot, or a wave whose boxes stopped fitting its LDS region and that would gather from the rows from here on)
+            const bool use_twin = many_lines && L.twin == 1u;
 
             // ---- empty-space skipping (LMIP mode; host: MarchParams::cells_all).  Per LOD the host keeps, for
             // cells of S^3 ring slots (S = 8 or 4), the largest value stored in the 2 x 2 x 2 block of cells that
@@ -1302,6 +1302,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
             // ---- direct fast batches: texel offset = ((iz*Ry + iy)*Rx + ix)*es + Kc, U loads in flight
             // (two copies of the loop, one per layout the wave gathers from: each keeps only its own constants live)
+            __amdgpu_buffer_rsrc_t rsrc_twin = rsrc;              // (the copy's own resource: set where the wave turns to it)
             auto direct_batches = [&](auto from_twin) {
             constexpr bool TW = decltype(from_twin)::value;
             for (; run > 0; --run) {
@@ -1386,7 +1387,12 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                 n += U;
             }
             };
-            if (use_twin) direct_batches(std::true_type{}); else direct_batches(std::false_type{});
+            if (use_twin || (many_lines && L.twin == 2u && (brick_mode == 0 || L.slab <= 0))) {
+                rsrc_twin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.twin_rbytes, 0x00020000);
+                direct_batches(std::true_type{});
+            } else {
+                direct_batches(std::false_type{});
+            }
             } while (held > 0 && __builtin_amdgcn_ballot_w64(alive && !finished && n < nsteps) != 0);
             lap(6);
         }

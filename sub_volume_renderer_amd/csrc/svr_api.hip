@@ -58,7 +58,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
                     "svr_create: density_storage must be SVR_F32, SVR_U8 or SVR_U16");
         SVR_REQUIRE(lods[l].density_storage == lods[0].density_storage,
                     "svr_create: all LODs must use the same density_storage");
-        SVR_REQUIRE(lods[l].blocked_twin == 0 || lods[l].blocked_twin == 1, "svr_create: blocked_twin must be 0 or 1");
+        SVR_REQUIRE(lods[l].blocked_twin >= 0 && lods[l].blocked_twin <= 2, "svr_create: blocked_twin must be 0, 1 or 2");
         SVR_REQUIRE(!lods[l].blocked_twin ||
                     (lods[l].ring_dims[0] % 8 == 0 && lods[l].ring_dims[1] % 4 == 0 && lods[l].ring_dims[2] % 4 == 0),
                     "svr_create: blocked_twin needs ring extents that are multiples of (8, 4, 4)");
@@ -76,7 +76,7 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     c->uploads_marker = nullptr; c->marker_set = false; c->dbg_dev = nullptr;
     for (auto& s : c->slot) { s.host = s.dev = nullptr; s.done = nullptr; s.used = false; }
     for (int l = 0; l < SVR_MAX_LODS; ++l) { c->lod[l].density = nullptr; c->lod[l].twin = nullptr; c->lod[l].labels = nullptr; c->lod[l].voxels = 0; }
-    c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0;
+    c->density_all = nullptr; c->labels_all = nullptr; c->density_all_bytes = 0; c->twin_all = nullptr; c->twin_all_bytes = 0;
     c->cells_raw_all = c->cells_dil_all = nullptr; c->cells_all_bytes = 0;
     c->density_storage = lods[0].density_storage;
     c->no_labels = lods[0].no_labels != 0 ? 1 : 0;
@@ -102,24 +102,28 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
         c->lod_base_bytes[l] = total;                         // voxel offset of this LOD
         total += (L.voxels + 255) & ~(size_t)255;
     }
-    // the micro-block copies (svr_lod_desc::blocked_twin) follow the rings in the density allocation: while all of it
-    // stays below 4 GiB, one buffer resource reaches the rings and their copies alike
+    // the micro-block copies (svr_lod_desc::blocked_twin) live in an allocation of their own, each behind a buffer resource
+    // of its own: the copies must not push the RINGS over the 4 GiB below which one resource reaches every LOD (the faster
+    // build of the march; config 5's byte rings are 2.4 GB, with their copies 4.8)
     const size_t ring_voxels = total;
-    size_t twin_base[SVR_MAX_LODS] = {0};
+    size_t twin_base[SVR_MAX_LODS] = {0}, twin_voxels = 0;
     for (int l = 0; l < num_lods; ++l) {
         if (!lods[l].blocked_twin) continue;
-        twin_base[l] = total;
-        total += (c->lod[l].voxels + 255) & ~(size_t)255;
+        twin_base[l] = twin_voxels;
+        twin_voxels += (c->lod[l].voxels + 255) & ~(size_t)255;
     }
     const size_t des = svr_dtype_size(c->density_storage);
     c->density_all_bytes = total * des + 64;                 // + slack: 16-byte brick loads may overrun a row end
+    c->twin_all_bytes = twin_voxels ? twin_voxels * des + 64 : 0;
     // one allocation per plane type; zero-initialised textures (_wrapping_buffer.py:50-59)
     if (hipMalloc((void**)&c->density_all, c->density_all_bytes) != hipSuccess ||
+        (c->twin_all_bytes && hipMalloc((void**)&c->twin_all, c->twin_all_bytes) != hipSuccess) ||
         (!c->no_labels && hipMalloc((void**)&c->labels_all, ring_voxels * sizeof(uint32_t)) != hipSuccess)) {
         svr_set_error("svr_create: out of device memory for ring textures");
         return fail(SVR_ERR_NOMEM);
     }
     if (hipMemsetAsync(c->density_all, 0, c->density_all_bytes, c->upload_stream) != hipSuccess ||
+        (c->twin_all_bytes && hipMemsetAsync(c->twin_all, 0, c->twin_all_bytes, c->upload_stream) != hipSuccess) ||
         (!c->no_labels && hipMemsetAsync(c->labels_all, 0, ring_voxels * sizeof(uint32_t), c->upload_stream) != hipSuccess)) {
         svr_set_error("svr_create: memset failed");
         return fail(SVR_ERR_HIP);
@@ -127,7 +131,8 @@ int svr_create(int device, int num_lods, const svr_lod_desc* lods, svr_ctx** out
     for (int l = 0; l < num_lods; ++l) {
         c->lod[l].density = static_cast<char*>(c->density_all) + c->lod_base_bytes[l] * des;
         c->lod[l].labels = c->no_labels ? nullptr : c->labels_all + c->lod_base_bytes[l];
-        c->lod[l].twin = lods[l].blocked_twin ? static_cast<char*>(c->density_all) + twin_base[l] * des : nullptr;
+        c->lod[l].twin = lods[l].blocked_twin ? static_cast<char*>(c->twin_all) + twin_base[l] * des : nullptr;
+        c->lod[l].twin_policy = lods[l].blocked_twin;
     }
     {   // macro-cell maxima (empty-space skipping): one grid of cells per LOD whose extents are multiples of 8.
         // The finest level gets 8^3-slot cells, the coarser ones 4^3: their structures are half / a quarter the size
@@ -177,6 +182,7 @@ int svr_destroy(svr_ctx* c) {
     if (c->render_stream) (void)hipStreamSynchronize(c->render_stream);
     if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
     if (c->density_all) (void)hipFree(c->density_all);
+    if (c->twin_all) (void)hipFree(c->twin_all);
     if (c->labels_all) (void)hipFree(c->labels_all);
     if (c->cells_raw_all) (void)hipFree(c->cells_raw_all);
     if (c->cells_dil_all) (void)hipFree(c->cells_dil_all);
@@ -1060,13 +1066,12 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
     for (int l = 0; l < c->num_lods; ++l) {
         LodParams& Q = P.lod[l];
         Q.nparts = 1u; Q.zsplit = Q.ring[2]; Q.part_bytes = 0u; Q.rbytes_last = 0u;
-        // the micro-block copy of the ring (svr_lod_desc::blocked_twin): inside the one resource, or a resource of its own
-        // that is cut into parts exactly like the ring's (parts of whole blocks: zsplit is a multiple of 4 planes)
+        // the micro-block copy of the ring (svr_lod_desc::blocked_twin): always behind a resource of its own, which is cut
+        // into parts exactly like the ring's where that is (parts of whole blocks: zsplit is a multiple of 4 planes)
         // (the march addresses it from the packed voxel index y | z << 16: both below 2^16, whatever the ray)
-        Q.twin = (c->lod[l].twin && P.size[1] * Q.scale[1] < 65536.0f && P.size[2] * Q.scale[2] < 65536.0f) ? 1u : 0u;
-        Q.twin_base_bytes = (!P.per_lod_rsrc && c->lod[l].twin)
-                                ? (uint32_t)(static_cast<const char*>(c->lod[l].twin) - static_cast<const char*>(c->density_all)) : 0u;
-        Q.twin_rbase = P.per_lod_rsrc ? c->lod[l].twin : c->density_all;
+        Q.twin = (c->lod[l].twin && P.size[1] * Q.scale[1] < 65536.0f && P.size[2] * Q.scale[2] < 65536.0f) ? (uint32_t)c->lod[l].twin_policy : 0u;
+        Q.twin_rbase = c->lod[l].twin;
+        Q.twin_rbytes = (uint32_t)std::min<uint64_t>((uint64_t)c->lod[l].voxels * svr_dtype_size(c->density_storage) + 64, 0xFFFFFFFFull);
         if (P.per_lod_rsrc) {
             const uint64_t des64 = svr_dtype_size(c->density_storage);
             const uint64_t plane = (uint64_t)Q.ring[0] * (uint64_t)Q.ring[1] * des64, bytes = (uint64_t)c->lod[l].voxels * des64;
@@ -1089,6 +1094,7 @@ static int fill_params(svr_ctx* c, const svr_camera* cam, const svr_frame* fr, c
                 Q.part_bytes = Q.rbytes = (uint32_t)((uint64_t)Q.zsplit * plane);
                 Q.rbytes_last = (uint32_t)(bytes - (uint64_t)(Q.nparts - 1) * Q.part_bytes + 64);
             }
+            Q.twin_rbytes = Q.rbytes;                       // (a full part's size where the ring is cut; part_rsrc sizes the last one)
         } else {
             Q.rbase = c->density_all; Q.rbytes = P.density_all_bytes;
         }

@@ -60,9 +60,9 @@ struct LodParams {
     uint32_t rbytes_last;
     // svr_lod_desc::blocked_twin: a second copy of this ring in 128-byte micro-blocks (svr_blocked_index).  It is split into
     // parts exactly like the ring (same zsplit — a whole number of blocks —, part sizes and count)
-    uint32_t twin;             // 1: the copy exists
-    uint32_t twin_base_bytes;  // its byte offset inside the one-resource allocation (per_lod_rsrc = 0; a multiple of 256)
-    const void* twin_rbase;    // per_lod_rsrc = 1: its own resource starts here
+    uint32_t twin;             // 0: no copy; 1: waves with many rows per gather take it instead of staging bricks; 2: only when they stage none
+    uint32_t twin_rbytes;      // size of the copy's own buffer resource (of a full part of it where the ring is cut into parts)
+    const void* twin_rbase;    // ... which starts here
     uint32_t cell_base;        // byte offset of the LOD's cell grid
     uint32_t cdim[3];          // cells per axis
     int32_t  cshift;           // log2 of the cell size (3 or 2)
@@ -136,6 +136,7 @@ struct LodStorage {
     size_t   voxels;
     void*     density;
     void*     twin;            // micro-block copy of `density` (svr_lod_desc::blocked_twin) or null
+    int32_t   twin_policy;     // svr_lod_desc::blocked_twin as given: 1 instead of bricks, 2 where no bricks are staged
     uint32_t* labels;
     svr_lod_state state;
     // macro-cell maxima (8^3 or 4^3 slots per cell) for empty-space skipping; null when an extent is not a multiple of 8
@@ -158,6 +159,8 @@ struct svr_ctx {
     int num_lods;
     LodStorage lod[SVR_MAX_LODS];
     void*     density_all;           // one allocation, LOD rings at 256-byte aligned offsets
+    void*     twin_all;              // the micro-block copies of the rings that keep one (svr_lod_desc::blocked_twin)
+    size_t    twin_all_bytes;
     int       density_storage;       // ring element type: SVR_F32 (reference layout), SVR_U8 or SVR_U16
     int       density_u8;            // density_storage == SVR_U8
     int       no_labels;             // the volume has no segmentation: no label rings

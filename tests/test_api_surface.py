@@ -249,11 +249,13 @@ def test_blocked_twin_argument():
     from sub_volume_renderer_amd._wrapping_buffer import blocked_twin_lods
 
     shapes = [(64, 64, 64), (32, 32, 32), (30, 32, 32), (32, 32, 36)]                # numpy order: the last two do not fit
-    assert blocked_twin_lods(shapes, "auto") == [True, False, False, False]
-    assert blocked_twin_lods(shapes[2:], "auto") == [False, False]
-    assert blocked_twin_lods(shapes, True) == [True, True, False, False]
-    assert blocked_twin_lods(shapes, False) == [False] * 4
-    assert blocked_twin_lods(shapes, [False, True, False, False]) == [False, True, False, False]
+    # per LOD: 0 no copy, 1 a copy taken instead of staging bricks, 2 a copy for waves that stage none
+    assert blocked_twin_lods(shapes, "auto") == [1, 2, 0, 0]
+    assert blocked_twin_lods(shapes[2:], "auto") == [0, 0]
+    assert blocked_twin_lods(shapes, True) == [1, 1, 0, 0]
+    assert blocked_twin_lods(shapes, False) == [0] * 4
+    assert blocked_twin_lods(shapes, [False, True, False, False]) == [0, 1, 0, 0]
+    assert blocked_twin_lods(shapes, [2, "fallback", 0, False]) == [2, 2, 0, 0]
     with pytest.raises(ValueError):
         blocked_twin_lods(shapes, [True, True, True, False])
     with pytest.raises(ValueError):
@@ -286,9 +288,9 @@ def test_auto_twin_is_given_up_when_the_device_has_no_room(monkeypatch):
 
     monkeypatch.setattr(_native, "lib", lambda: FakeLib())
     rings = DeviceRings([(64, 64, 64), (32, 32, 32)], device=0, density_storage="uint8")
-    assert rings.blocked_twin == [True, False]
+    assert rings.blocked_twin == [1, 2]
     assert rings.handle.value == 0x1234
-    assert calls == [[1, 0], [0, 0]] and rings.blocked_twin == [False, False]
+    assert calls == [[1, 2], [0, 0]] and rings.blocked_twin == [0, 0]
     calls.clear()
     wanted = DeviceRings([(64, 64, 64)], device=0, density_storage="uint8", blocked_twin=True)
     with pytest.raises(MemoryError):
