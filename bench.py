@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--ring-storage", choices=["native", "float32"], default="native",
                     help="native: byte rings for the uint8 volume (identical results); float32: reference layout")
+    ap.add_argument("--blocked-twin-all", action="store_true",
+                    help="also keep micro-block copies of the coarser LODs, for waves that stage no bricks (blocked_twin='all')")
     ap.add_argument("--no-blocked-twin", action="store_true",
                     help="density rings in rows only: no micro-block copy of the finest LOD (svr_lod_desc::blocked_twin; A/B)")
     ap.add_argument("--float32-block", action="store_true", help="C5: measure the float32-ring block too (C2 does by default)")
@@ -338,6 +340,8 @@ def main():
     spec.ring_storage = args.ring_storage
     if args.no_blocked_twin:
         spec.blocked_twin = False
+    elif args.blocked_twin_all:
+        spec.blocked_twin = "all"
 
     def source_stats(reset=False):
         """(seconds inside the backing arrays' reads, decoded bytes handed out, stored bytes read) since the last reset:
@@ -538,7 +542,8 @@ def main():
         tools/profile_bench.sh: rocprofv3 cannot run from inside the process it profiles), or a note why there are none."""
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")
         here = dict(config=cfg, n=n, width=W, height=H, camera=camera, variant=args.variant,
-                    ring_storage=ring_storage, blocked_twin=not args.no_blocked_twin, kernel_source_sha16=kernel_source_hash())
+                    ring_storage=ring_storage, blocked_twin=not (args.no_blocked_twin or args.blocked_twin_all),
+                    kernel_source_sha16=kernel_source_hash())
         if not os.path.exists(tpath):
             return None, None
         with open(tpath) as f:

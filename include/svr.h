@@ -79,7 +79,7 @@ typedef struct svr_lod_desc {
                                       element per voxel of HBM and of upload traffic; results are identical.  The copies have an
                                       allocation of their own (they never push the rings over the 4 GiB below which one buffer
                                       resource reaches every LOD).  ring_dims must be multiples of (8, 4, 4), else SVR_ERR_INVALID.
-                                      The Python mirror's "auto": 1 on the finest LOD, 2 on the others, where the extents allow. */
+                                      The Python mirror's "auto": 1 on the finest LOD; "all": also 2 on the others. */
 } svr_lod_desc;
 
 /* == u_wrapping_buffer_i uniform (_wrapping_buffer.py:15-19), shader order.

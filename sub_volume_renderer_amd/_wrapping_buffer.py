@@ -46,9 +46,10 @@ class DeviceRings:
         self.labels = bool(labels)            # False: a volume without segmentation, no label rings at all
         # Which LODs keep a second copy of their density ring in 128-byte micro-blocks (svr_lod_desc::blocked_twin), and
         # what for — per LOD 0 (none), 1 (waves whose gathers touch many rows take it INSTEAD of staging bricks) or 2 (only
-        # where such a wave stages no bricks: "fallback").  "auto" = 1 for the finest LOD, 2 for the others, wherever the
-        # extents allow (multiples of (8, 4, 4) in x, y, z); True = 1 for every LOD whose extents allow; False = none; or one
-        # value per LOD (False / True / 2 / "fallback"; an extent that does not allow it is a ValueError then).
+        # where such a wave stages no bricks: "fallback").  "auto" = 1 for the finest LOD when its extents allow (multiples of
+        # (8, 4, 4) in x, y, z); "all" = that plus 2 for the coarser LODs whose extents allow (views whose slab boxes do not
+        # fit the LDS regions gain 10 - 16 %, every upload of every LOD writes twice); True = 1 for every LOD whose extents
+        # allow; False = none; or one value per LOD (False / True / 2 / "fallback"; an extent that does not allow: ValueError).
         self.blocked_twin = blocked_twin_lods(self.ring_shapes, blocked_twin)
         self._twin_optional = isinstance(blocked_twin, str)      # "auto": the copy is given up when the device has no room for it
         self._handle = None
@@ -148,9 +149,9 @@ def blocked_twin_lods(ring_shapes, blocked_twin="auto") -> list[int]:
     staging bricks, 2 a copy for waves that stage none.  (ring_shapes in numpy order)"""
     fits = [s[2] % 8 == 0 and s[1] % 4 == 0 and s[0] % 4 == 0 for s in ring_shapes]
     if isinstance(blocked_twin, str):
-        if blocked_twin != "auto":
-            raise ValueError("blocked_twin must be 'auto', a bool or one value per LOD")
-        return [(1 if i == 0 else 2) if ok else 0 for i, ok in enumerate(fits)]
+        if blocked_twin not in ("auto", "all"):
+            raise ValueError("blocked_twin must be 'auto', 'all', a bool or one value per LOD")
+        return [(1 if i == 0 else (2 if blocked_twin == "all" else 0)) if ok else 0 for i, ok in enumerate(fits)]
     if isinstance(blocked_twin, (bool, np.bool_)):
         return [1 if (blocked_twin and ok) else 0 for ok in fits]
     wanted = [2 if (v == "fallback" or (v == 2 and v is not True)) else (1 if v else 0) for v in blocked_twin]

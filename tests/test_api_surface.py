@@ -250,8 +250,9 @@ def test_blocked_twin_argument():
 
     shapes = [(64, 64, 64), (32, 32, 32), (30, 32, 32), (32, 32, 36)]                # numpy order: the last two do not fit
     # per LOD: 0 no copy, 1 a copy taken instead of staging bricks, 2 a copy for waves that stage none
-    assert blocked_twin_lods(shapes, "auto") == [1, 2, 0, 0]
-    assert blocked_twin_lods(shapes[2:], "auto") == [0, 0]
+    assert blocked_twin_lods(shapes, "auto") == [1, 0, 0, 0]
+    assert blocked_twin_lods(shapes, "all") == [1, 2, 0, 0]
+    assert blocked_twin_lods(shapes[2:], "auto") == [0, 0] and blocked_twin_lods(shapes[2:], "all") == [0, 0]
     assert blocked_twin_lods(shapes, True) == [1, 1, 0, 0]
     assert blocked_twin_lods(shapes, False) == [0] * 4
     assert blocked_twin_lods(shapes, [False, True, False, False]) == [0, 1, 0, 0]
@@ -287,7 +288,7 @@ def test_auto_twin_is_given_up_when_the_device_has_no_room(monkeypatch):
             return 0
 
     monkeypatch.setattr(_native, "lib", lambda: FakeLib())
-    rings = DeviceRings([(64, 64, 64), (32, 32, 32)], device=0, density_storage="uint8")
+    rings = DeviceRings([(64, 64, 64), (32, 32, 32)], device=0, density_storage="uint8", blocked_twin="all")
     assert rings.blocked_twin == [1, 2]
     assert rings.handle.value == 0x1234
     assert calls == [[1, 2], [0, 0]] and rings.blocked_twin == [0, 0]

@@ -71,24 +71,24 @@ def test_frames_with_the_micro_block_copy_are_the_oracles_and_those_without_it(c
     assert same and all(same.values()), same
 
 
-@pytest.mark.parametrize("which", ["all", "middle", "auto", "fallback_only"])
+@pytest.mark.parametrize("which", ["instead_everywhere", "middle", "all", "fallback_only"])
 @pytest.mark.parametrize("storage", ["native", "float32"])
 def test_copies_of_several_lods_and_of_a_coarser_one_alone(which, storage):
-    """`blocked_twin=True` (every LOD whose extents allow, instead of bricks), a copy of LOD 1 only, the default ("auto": the
-    finest LOD instead of bricks, the coarser ones for waves that stage none) and copies that are all of the second kind:
+    """`blocked_twin=True` (every LOD whose extents allow, instead of bricks), a copy of LOD 1 only, "all" (the finest LOD
+    instead of bricks, the coarser ones for waves that stage none) and copies that are all of the second kind:
     frames stay the oracle's.  (float32 rings of this size stage no bricks from LOD 0 — their boxes do not fit — so the
     second kind is what serves it there.)"""
     spec = _spec(96, storage, "diag")
-    spec.blocked_twin = {"all": True, "middle": [False, True, False], "auto": "auto", "fallback_only": [2, 2, "fallback"]}[which]
+    spec.blocked_twin = {"instead_everywhere": True, "middle": [False, True, False], "all": "all", "fallback_only": [2, 2, "fallback"]}[which]
     scene = testing.build(spec)
-    assert scene.volume._rings.blocked_twin == {"all": [1, 1, 1], "middle": [0, 1, 0], "auto": [1, 2, 2], "fallback_only": [2, 2, 2]}[which]
+    assert scene.volume._rings.blocked_twin == {"instead_everywhere": [1, 1, 1], "middle": [0, 1, 0], "all": [1, 2, 2], "fallback_only": [2, 2, 2]}[which]
     check(scene)                                                           # the waves' own probes first
     N.check(N.lib().svr_set_variant(scene.volume.prepare(), ALWAYS), "svr_set_variant")
     twin_batches(scene.volume)
     check(scene)
     used = twin_batches(scene.volume)
     assert used > 0 or which == "fallback_only"                            # (copies of the second kind serve only waves without bricks)
-    if which in ("auto", "fallback_only"):
+    if which in ("all", "fallback_only"):
         # no LOD of this volume may stage bricks (svr_set_variant bits 24-31: only LOD 6 may): every copy of the second kind serves
         N.check(N.lib().svr_set_variant(scene.volume.prepare(), ALWAYS | (0x40 << 24)), "svr_set_variant")
         twin_batches(scene.volume)

@@ -13,10 +13,10 @@ from sub_volume_renderer_amd import _native as N  # noqa: E402
 cam = sys.argv[1] if len(sys.argv) > 1 else "K1"
 storage = sys.argv[2] if len(sys.argv) > 2 else "native"
 config = sys.argv[3] if len(sys.argv) > 3 else "C2"
-twin = sys.argv[4] if len(sys.argv) > 4 else "twin"      # twin: the default ("auto": LOD 0 instead of bricks, coarser LODs where no bricks are staged);
-                                                          # twin0: LOD 0 only; notwin: rows only
+twin = sys.argv[4] if len(sys.argv) > 4 else "twin"      # twin: the default ("auto": a micro-block copy of LOD 0, taken instead of bricks);
+                                                          # twinall: + copies of the coarser LODs for waves that stage no bricks; notwin: rows only
 W, H = 1920, 1080
-scene, spec = build_scene(config, None, cam, storage, W, H, blocked_twin={"twin": "auto", "twin0": [True, False, False], "notwin": False}[twin])
+scene, spec = build_scene(config, None, cam, storage, W, H, blocked_twin={"twin": "auto", "twinall": "all", "notwin": False}[twin])
 vol = scene.volume
 variant = int(os.environ.get("EXP_VARIANT", "0"), 0)                   # svr_set_variant bits for the run (include/svr.h)
 N.check(N.lib().svr_set_variant(vol.prepare(), variant), "svr_set_variant")
@@ -34,4 +34,4 @@ for mode in ("full", "lmip"):
         N.check(N.lib().svr_time_render(vol._rings.handle, C.byref(cb), C.byref(fb), C.byref(ob), 10, C.byref(ms)), "time")
         vals.append(ms.value)
     out.append(sorted(vals)[1])
-print(f"{config} {storage:8s} {cam:5s} {twin:6s} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms" + (f"   variant {variant:#x}" if variant else ""), flush=True)
+print(f"{config} {storage:8s} {cam:5s} {twin:7s} full {out[0]:.4f} ms   lmip {out[1]:.4f} ms" + (f"   variant {variant:#x}" if variant else ""), flush=True)
