@@ -513,23 +513,11 @@ __device__ __forceinline__ uint32_t shl_add_c(uint32_t a, uint32_t c) {         
 template <int ESH> struct TwinBlock { static constexpr int XB = ESH == 0 ? 3 : 2, YB = 2, ZB = ESH == 2 ? 1 : 2; };
 // Byte offset of the texel of voxel (x, y, z) in that copy, for a lane whose ring slot is voxel + (kx, ky, kz) with
 // constants that are multiples of the ring extents — and therefore of the block extents: the block coordinates of the
-// slot are those of the voxel plus constants, the position inside the block is the voxel's own low bits.  Kb = the
-// constants' part of the block number (+ the copy's offset in the resource, in blocks); all mod 2^32.
-template <int ESH>
-__device__ __forceinline__ uint32_t twin_offset(uint32_t x, uint32_t y, uint32_t z, int nbx, int nby, uint32_t Kb) {
-    typedef TwinBlock<ESH> B;
-    const int bx = (int)x >> B::XB, by = (int)y >> B::YB, bz = (int)z >> B::ZB;        // (arithmetic: a voxel index may be negative)
-    // (written out: from `__mul24(bz, nby) + by` the compiler makes a v_mad_u64_u32, a quarter-rate instruction)
-    // (voxel indices are non-negative below 2^23 on this path, like the row-major form's: MarchParams::lod_pow2)
-    // (builtins, not the asm mad24 of the row-major form: with even one asm statement here the kernel takes 101 VGPRs instead
-    //  of 92 — one wave per SIMD less; the price is a v_mad_u64_u32 for the inner multiply-add)
-    const uint32_t blk = __umul24(__umul24((uint32_t)bz, (uint32_t)nby) + (uint32_t)by, (uint32_t)nbx) + (uint32_t)bx;
-    const uint32_t inb = ((((z & ((1u << B::ZB) - 1u)) << B::YB) | (y & 3u)) << B::XB) | (x & ((1u << B::XB) - 1u));
-    return ((blk + Kb) << 7) | (inb << ESH);
-}
-
-// The same from the packed form of the voxel (x, yz = y | z << 16, both below 2^16: LodParams::twin says so) in 8 VALU
-// operations (byte rings; 9 otherwise) where the plain form takes 12:
+// slot are those of the voxel plus constants, the position inside the block is the voxel's own low bits:
+//   offset = ((z >> ZB) * NBy + (y >> YB)) * NBx + (x >> XB) + Kb) * 128 + in-block part,   Kb = the constants' block number
+// (all mod 2^32).  Computed from the packed form of the voxel (x, yz = y | z << 16, both below 2^16: LodParams::twin says
+// so) in 9 VALU operations, where the form above takes 12 and a quarter-rate v_mad_u64_u32 (the compiler's choice for the
+// inner multiply-add; the asm mad24 of the row-major form costs this loop 9 more VGPRs — one wave per SIMD less):
 //   offset = 4row * (NBx * 32) + (x & ~xm) << (7 - XB)  +  [ (y & 3) * wy + (z & zm) * wz + ((x & xm) << ESH | KbS) ]
 // with 4row = (y & ~3) + (z & ~zm) * (NBy * 4 >> ZB) from one v_dot2_u32_u16, the bracket from another (wy, wz: the byte
 // strides of y and z inside a block) and KbS = Kb << 7 (its low 7 bits are free for the in-block part).
