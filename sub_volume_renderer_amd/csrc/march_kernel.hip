@@ -649,8 +649,8 @@ struct LodK {
     const void* rbase;
     uint32_t rbytes;
     uint32_t nparts, zsplit, part_bytes, rbytes_last;      // rings of 4 GiB or more: parts of zsplit planes (LodParams)
-    uint32_t twin, twin_rbytes;                            // micro-block copy of the ring (LodParams::twin)
-    const void* twin_rbase;
+    uint32_t twin;                                         // micro-block copy of the ring (LodParams::twin; its resource is read where
+                                                           // a wave turns to it, not kept live across the brick loop)
 };
 __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     LodK k;
@@ -661,7 +661,7 @@ __device__ __forceinline__ LodK load_lod(kparams_t p, int l) {
     k.rx4 = p->lod[l].rx4; k.base_bytes = p->lod[l].base_bytes; k.slab = p->lod[l].slab;
     k.rbase = p->lod[l].rbase; k.rbytes = p->lod[l].rbytes;
     k.nparts = p->lod[l].nparts; k.zsplit = p->lod[l].zsplit; k.part_bytes = p->lod[l].part_bytes; k.rbytes_last = p->lod[l].rbytes_last;
-    k.twin = p->lod[l].twin; k.twin_rbytes = p->lod[l].twin_rbytes; k.twin_rbase = p->lod[l].twin_rbase;
+    k.twin = p->lod[l].twin;
     return k;
 }
 
@@ -1290,7 +1290,8 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
 
             // ---- direct fast batches: texel offset = ((iz*Ry + iy)*Rx + ix)*es + Kc, U loads in flight
             // (two copies of the loop, one per layout the wave gathers from: each keeps only its own constants live)
-            __amdgpu_buffer_rsrc_t rsrc_twin = rsrc;              // (the copy's own resource: set where the wave turns to it)
+            __amdgpu_buffer_rsrc_t rsrc_twin = rsrc;              // (the copy's own resource and base: set where the wave turns to it)
+            const void* twin_base = nullptr;
             auto direct_batches = [&](auto from_twin) {
             constexpr bool TW = decltype(from_twin)::value;
             for (; run > 0; --run) {
@@ -1337,7 +1338,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                     const uint32_t pa = part_of((int)ez2.x), pb = part_of((int)ez2.y);
                     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pa, (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(live)));
                     if (__builtin_amdgcn_ballot_w64(live && (pa != p0 || pb != p0)) == 0) {
-                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0, TW ? L.twin_rbase : L.rbase);
+                        const __amdgpu_buffer_rsrc_t rp = part_rsrc(L, p0, TW ? twin_base : L.rbase);
                         const uint32_t sub = p0 * L.part_bytes;
 #pragma unroll
                         for (int u = 0; u < U; ++u) s[u] = fetch_density<ESH>(rp, live ? off[u] - sub : 0xFFFFFFFFu);
@@ -1357,7 +1358,7 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
                             for (unsigned long long todo = __builtin_amdgcn_ballot_w64(live); todo != 0ull;) {
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)part, (int)__builtin_ctzll(todo));
                                 const bool mine = live && part == p;
-                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p, TW ? L.twin_rbase : L.rbase), mine ? rel : 0xFFFFFFFFu);
+                                const texel_t t = fetch_density<ESH>(part_rsrc(L, p, TW ? twin_base : L.rbase), mine ? rel : 0xFFFFFFFFu);
                                 a = mine ? t : a;
                                 todo &= ~__builtin_amdgcn_ballot_w64(mine);
                             }
@@ -1376,7 +1377,9 @@ __global__ __launch_bounds__(256) void march_span(const MarchParams P) {
             }
             };
             if (use_twin || (many_lines && L.twin == 2u && (brick_mode == 0 || L.slab <= 0))) {
-                rsrc_twin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(L.twin_rbase), 0, (int)L.twin_rbytes, 0x00020000);
+                const kparams_t Pt = fresh_params(P);
+                twin_base = Pt->lod[first].twin_rbase;
+                rsrc_twin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(twin_base), 0, (int)Pt->lod[first].twin_rbytes, 0x00020000);
                 direct_batches(std::true_type{});
             } else {
                 direct_batches(std::false_type{});
